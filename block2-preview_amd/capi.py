@@ -1,0 +1,189 @@
+"""ctypes binding of the C ABI in include/b2x.h (libb2x.so, built in-tree by __graft_entry__.build()).
+
+This is the reference-side binding a Python host would use; the pybind/C++ host of block2 would bind
+the same symbols.  There is deliberately no fallback: if libb2x.so is missing, or no
+gfx950 device is present, the compute entry points raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .planfile import PAIR_DTYPE
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libb2x.so")
+
+# every symbol include/b2x.h declares (checked by tests/test_capi_symbols.py)
+DECLARED_SYMBOLS = [
+    "b2x_last_error", "b2x_version", "b2x_device_count", "b2x_device_init", "b2x_device_sync",
+    "b2x_device_alloc", "b2x_device_free", "b2x_memcpy_h2d", "b2x_memcpy_d2h",
+    "b2x_arena_create", "b2x_arena_adopt_device", "b2x_arena_resolve", "b2x_arena_len",
+    "b2x_arena_device_ptr", "b2x_arena_destroy",
+    "b2x_plan_create", "b2x_plan_execute", "b2x_plan_get_stats", "b2x_plan_time_kernel", "b2x_plan_destroy",
+    "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
+    "b2x_vec_multi_dot", "b2x_vec_lincomb",
+]
+
+
+class PlanStats(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in (
+        "n_pairs", "macs", "op_elems_unique", "psi_len", "sigma_len", "n_targets", "n_tiles", "n_items",
+        "n_parts", "device_bytes", "macs_executed", "dominant_class", "macs_dominant")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+class PlanOptions(C.Structure):
+    _fields_ = [("tile_m", C.c_int32), ("tile_n", C.c_int32), ("kernel", C.c_int32), ("_pad", C.c_int32),
+                ("item_macs", C.c_int64), ("reserved", C.c_int32 * 8)]
+
+
+class B2XError(RuntimeError):
+    """Non-zero return from the C ABI (the reference throws runtime_error at this boundary)."""
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise B2XError("libb2x.so is not built (%s); run __graft_entry__.build()" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.b2x_last_error.restype = C.c_char_p
+        _lib.b2x_version.restype = C.c_char_p
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise B2XError("b2x error %d: %s" % (rc, lib().b2x_last_error().decode()))
+
+
+def _ptr(a):
+    """device pointer (int) or numpy array -> c_void_p"""
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data_as(C.c_void_p)
+    return C.c_void_p(int(a))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().b2x_device_count(C.byref(n)))
+    return n.value
+
+
+def device_init(ordinal=0):
+    check(lib().b2x_device_init(C.c_int(ordinal)))
+
+
+def device_sync():
+    check(lib().b2x_device_sync())
+
+
+class Arena:
+    """Operator blocks resident in HBM (OperatorTensor::ops[*]->data of the reference)."""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep
+
+    @classmethod
+    def from_host(cls, arrays):
+        arrays = [np.ascontiguousarray(a, np.float64) for a in arrays]
+        n = len(arrays)
+        bases = (C.c_void_p * n)(*[a.ctypes.data for a in arrays])
+        lens = (C.c_size_t * n)(*[a.size for a in arrays])
+        h = C.c_void_p()
+        check(lib().b2x_arena_create(C.byref(h), C.c_size_t(n), bases, lens))
+        return cls(h, arrays)
+
+    @classmethod
+    def adopt_device(cls, dev_ptr, length, keep=None):
+        h = C.c_void_p()
+        check(lib().b2x_arena_adopt_device(C.byref(h), C.c_void_p(int(dev_ptr)), C.c_size_t(length)))
+        return cls(h, keep)
+
+    def __len__(self):
+        n = C.c_uint64()
+        check(lib().b2x_arena_len(self._h, C.byref(n)))
+        return n.value
+
+    def resolve(self, host_address):
+        off = C.c_uint64()
+        check(lib().b2x_arena_resolve(self._h, C.c_void_p(int(host_address)), C.byref(off)))
+        return off.value
+
+    def close(self):
+        if self._h is not None:
+            lib().b2x_arena_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Plan:
+    """Device-resident GEMM-pair plan (BatchGEMMSeq after precompute(), before post_precompute())."""
+
+    def __init__(self, arena, pairs, psi_len, sigma_len, kernel=0, tile_n=0, item_macs=0):
+        pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
+        opt = PlanOptions()
+        opt.kernel, opt.tile_n, opt.item_macs = kernel, tile_n, item_macs
+        h = C.c_void_p()
+        check(lib().b2x_plan_create(C.byref(h), arena._h, C.c_size_t(len(pairs)), _ptr(pairs), C.c_size_t(psi_len),
+                                    C.c_size_t(sigma_len), C.byref(opt)))
+        self._h, self._arena = h, arena
+        self.psi_len, self.sigma_len = psi_len, sigma_len
+
+    def execute_host(self, psi, sigma, scale=1.0):
+        """sigma += scale * H psi on host numpy arrays (copied through the device)."""
+        assert psi.dtype == np.float64 and sigma.dtype == np.float64
+        assert psi.size == self.psi_len and sigma.size == self.sigma_len
+        check(lib().b2x_plan_execute(self._h, _ptr(psi), _ptr(sigma), C.c_double(scale), C.c_int(0), None))
+
+    def execute_device(self, psi_ptr, sigma_ptr, scale=1.0, stream=0):
+        check(lib().b2x_plan_execute(self._h, C.c_void_p(int(psi_ptr)), C.c_void_p(int(sigma_ptr)), C.c_double(scale),
+                                     C.c_int(1), C.c_void_p(int(stream))))
+
+    def time_kernel(self, psi_ptr, sigma_ptr, n=3, stream=0):
+        a, b = C.c_double(), C.c_double()
+        check(lib().b2x_plan_time_kernel(self._h, C.c_void_p(int(psi_ptr)), C.c_void_p(int(sigma_ptr)), C.c_int(n),
+                                         C.c_void_p(int(stream)), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    @property
+    def stats(self):
+        st = PlanStats()
+        check(lib().b2x_plan_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def close(self):
+        if self._h is not None:
+            lib().b2x_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def debug_compile_and_emulate(pairs, psi_len, sigma_len, arena, psi, sigma, scale=1.0, tile_n=0, item_macs=0):
+    """TEST HOOK (not part of include/b2x.h): compile a plan and evaluate the compiled work list with
+    host loops, so the plan compiler can be verified without a GPU.  Returns (stats, fallback)."""
+    pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
+    opt = PlanOptions()
+    opt.tile_n, opt.item_macs = tile_n, item_macs
+    st, fb = PlanStats(), C.c_int(0)
+    check(lib().b2x_debug_compile_and_emulate(
+        C.c_size_t(len(pairs)), _ptr(pairs), C.c_size_t(psi_len), C.c_size_t(sigma_len), C.c_uint64(arena.size),
+        _ptr(arena), _ptr(psi), _ptr(sigma), C.c_double(scale), C.byref(opt), C.byref(st), C.byref(fb)))
+    return st.as_dict(), bool(fb.value)

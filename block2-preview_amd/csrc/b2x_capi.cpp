@@ -1,0 +1,425 @@
+// b2x_capi.cpp — implementation of the C ABI declared in include/b2x.h (HIP runtime glue).
+// No computation happens on the host here: plan_create compiles + uploads metadata, plan_execute
+// launches the gfx950 kernels.  Without a usable device every compute entry point fails loudly.
+#include "../../include/b2x.h"
+#include "b2x_kernels.h"
+#include "b2x_plan.hpp"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+
+using namespace b2x;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                                   \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            return fail(B2X_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                           \
+    } while (0)
+
+struct b2x_arena {
+    double *dev = nullptr;
+    uint64_t len = 0;
+    bool owned = false;
+    std::vector<const double *> host_bases; // sorted
+    std::vector<uint64_t> host_lens, offs;
+};
+
+struct b2x_plan {
+    const b2x_arena *arena = nullptr;
+    b2x_plan_stats stats{};
+    bool fallback = false;
+    int kernel = 0;
+    DPart *d_parts[kNumClasses] = {nullptr, nullptr, nullptr, nullptr};
+    DItem *d_items[kNumClasses] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t n_items[kNumClasses] = {0, 0, 0, 0};
+    DTile *d_tiles = nullptr;
+    uint32_t n_tiles = 0;
+    double *d_slabs = nullptr;
+    b2x_pair *d_pairs = nullptr; // generic kernel only
+    uint32_t n_pairs = 0;
+    double *d_psi = nullptr, *d_sigma = nullptr; // staging for host-pointer execute
+    size_t psi_len = 0, sigma_len = 0;
+    int dominant_cls = 0;
+};
+
+static void plan_free(b2x_plan *p) {
+    for (int k = 0; k < kNumClasses; k++) {
+        if (p->d_parts[k])
+            (void)hipFree(p->d_parts[k]);
+        if (p->d_items[k])
+            (void)hipFree(p->d_items[k]);
+    }
+    if (p->d_tiles)
+        (void)hipFree(p->d_tiles);
+    if (p->d_slabs)
+        (void)hipFree(p->d_slabs);
+    if (p->d_pairs)
+        (void)hipFree(p->d_pairs);
+    if (p->d_psi)
+        (void)hipFree(p->d_psi);
+    if (p->d_sigma)
+        (void)hipFree(p->d_sigma);
+    delete p;
+}
+
+template <typename T> static int upload(T **dst, const std::vector<T> &src) {
+    if (src.empty())
+        return B2X_OK;
+    HIPCHK(hipMalloc((void **)dst, src.size() * sizeof(T)));
+    HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return B2X_OK;
+}
+
+extern "C" {
+
+const char *b2x_last_error(void) { return g_err.c_str(); }
+const char *b2x_version(void) { return "b2x 0.1 (gfx950)"; }
+
+int b2x_device_count(int *n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess)
+        c = 0;
+    *n = c;
+    return B2X_OK;
+}
+
+int b2x_device_init(int ordinal) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess || c == 0)
+        return fail(B2X_ERR_DEVICE, "no HIP device visible: the H.psi path has no CPU fallback");
+    if (ordinal < 0 || ordinal >= c)
+        return fail(B2X_ERR_INVALID, "device ordinal out of range");
+    HIPCHK(hipSetDevice(ordinal));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, ordinal));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(B2X_ERR_DEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    return B2X_OK;
+}
+
+int b2x_device_sync(void) {
+    HIPCHK(hipDeviceSynchronize());
+    return B2X_OK;
+}
+int b2x_device_alloc(void **dptr, size_t bytes) {
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 8));
+    return B2X_OK;
+}
+int b2x_device_free(void *dptr) {
+    HIPCHK(hipFree(dptr));
+    return B2X_OK;
+}
+int b2x_memcpy_h2d(void *dst, const void *src, size_t bytes) {
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return B2X_OK;
+}
+int b2x_memcpy_d2h(void *dst, const void *src, size_t bytes) {
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return B2X_OK;
+}
+
+// ---------------------------------------------------------------------------------- arena
+int b2x_arena_create(b2x_arena **out, size_t n_ranges, const double *const *host_bases, const size_t *lens) {
+    if (!out || (n_ranges && (!host_bases || !lens)))
+        return fail(B2X_ERR_INVALID, "b2x_arena_create: null argument");
+    std::vector<size_t> order(n_ranges);
+    for (size_t i = 0; i < n_ranges; i++)
+        order[i] = i;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return host_bases[a] < host_bases[b]; });
+    b2x_arena *a = new b2x_arena();
+    uint64_t tot = 0;
+    for (size_t k = 0; k < n_ranges; k++) {
+        size_t i = order[k];
+        if (k > 0 && host_bases[i] < a->host_bases.back() + a->host_lens.back()) {
+            delete a;
+            return fail(B2X_ERR_INVALID, "b2x_arena_create: host ranges overlap");
+        }
+        a->host_bases.push_back(host_bases[i]);
+        a->host_lens.push_back(lens[i]);
+        a->offs.push_back(tot);
+        tot += lens[i];
+    }
+    a->len = tot, a->owned = true;
+    hipError_t e = hipMalloc((void **)&a->dev, (tot ? tot : 1) * sizeof(double));
+    if (e != hipSuccess) {
+        delete a;
+        return fail(B2X_ERR_NOMEM, std::string("hipMalloc(arena): ") + hipGetErrorString(e));
+    }
+    for (size_t k = 0; k < n_ranges; k++) {
+        e = hipMemcpy(a->dev + a->offs[k], a->host_bases[k], a->host_lens[k] * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(a->dev);
+            delete a;
+            return fail(B2X_ERR_DEVICE, std::string("hipMemcpy(arena): ") + hipGetErrorString(e));
+        }
+    }
+    *out = a;
+    return B2X_OK;
+}
+
+int b2x_arena_adopt_device(b2x_arena **out, double *dev_base, size_t len) {
+    if (!out || (!dev_base && len))
+        return fail(B2X_ERR_INVALID, "b2x_arena_adopt_device: null argument");
+    b2x_arena *a = new b2x_arena();
+    a->dev = dev_base, a->len = len, a->owned = false;
+    *out = a;
+    return B2X_OK;
+}
+
+int b2x_arena_resolve(const b2x_arena *a, const double *host_ptr, uint64_t *off) {
+    if (!a || !off)
+        return fail(B2X_ERR_INVALID, "b2x_arena_resolve: null argument");
+    auto it = std::upper_bound(a->host_bases.begin(), a->host_bases.end(), host_ptr);
+    if (it == a->host_bases.begin())
+        return fail(B2X_ERR_INVALID, "b2x_arena_resolve: pointer precedes every registered range");
+    size_t k = (size_t)(it - a->host_bases.begin()) - 1;
+    uint64_t d = (uint64_t)(host_ptr - a->host_bases[k]);
+    if (d >= a->host_lens[k])
+        return fail(B2X_ERR_INVALID, "b2x_arena_resolve: pointer is not inside a registered range");
+    *off = a->offs[k] + d;
+    return B2X_OK;
+}
+
+int b2x_arena_len(const b2x_arena *a, uint64_t *len) {
+    if (!a || !len)
+        return fail(B2X_ERR_INVALID, "b2x_arena_len: null argument");
+    *len = a->len;
+    return B2X_OK;
+}
+int b2x_arena_device_ptr(const b2x_arena *a, double **dev_base) {
+    if (!a || !dev_base)
+        return fail(B2X_ERR_INVALID, "b2x_arena_device_ptr: null argument");
+    *dev_base = a->dev;
+    return B2X_OK;
+}
+int b2x_arena_destroy(b2x_arena *a) {
+    if (!a)
+        return B2X_OK;
+    if (a->owned && a->dev)
+        (void)hipFree(a->dev);
+    delete a;
+    return B2X_OK;
+}
+
+// ---------------------------------------------------------------------------------- plan
+int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, const b2x_pair *pairs, size_t psi_len,
+                    size_t sigma_len, const b2x_plan_options *opt) {
+    if (!out || !arena || (n_pairs && !pairs))
+        return fail(B2X_ERR_INVALID, "b2x_plan_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(B2X_ERR_DEVICE, "b2x_plan_create: no HIP device (the H.psi path has no CPU fallback)");
+    CompiledPlan cp;
+    std::string err;
+    int rc = compile_plan(n_pairs, pairs, psi_len, sigma_len, arena->len, opt, cp, err);
+    if (rc != B2X_OK)
+        return fail(rc, "b2x_plan_create: " + err);
+    b2x_plan *p = new b2x_plan();
+    p->arena = arena, p->stats = cp.stats, p->psi_len = psi_len, p->sigma_len = sigma_len;
+    p->kernel = opt ? opt->kernel : 0;
+    p->fallback = cp.fallback || p->kernel == 1;
+    p->n_pairs = (uint32_t)n_pairs;
+    if (p->fallback) {
+        std::vector<b2x_pair> pv(pairs, pairs + n_pairs);
+        rc = upload(&p->d_pairs, pv);
+    } else {
+        size_t best = 0;
+        for (int k = 0; k < kNumClasses && rc == B2X_OK; k++) {
+            rc = upload(&p->d_parts[k], cp.cls[k].parts);
+            if (rc == B2X_OK)
+                rc = upload(&p->d_items[k], cp.cls[k].items);
+            p->n_items[k] = (uint32_t)cp.cls[k].items.size();
+            (void)best;
+        }
+        p->dominant_cls = (int)cp.stats.dominant_class;
+        if (rc == B2X_OK)
+            rc = upload(&p->d_tiles, cp.tiles);
+        p->n_tiles = (uint32_t)cp.tiles.size();
+        if (rc == B2X_OK && cp.slab_elems) {
+            hipError_t e = hipMalloc((void **)&p->d_slabs, cp.slab_elems * sizeof(double));
+            if (e != hipSuccess)
+                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
+        }
+    }
+    if (rc != B2X_OK) {
+        plan_free(p);
+        return rc;
+    }
+    *out = p;
+    return B2X_OK;
+}
+
+static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale, hipStream_t st) {
+    if (p->fallback) {
+        HIPCHK(launch_generic(p->d_pairs, p->n_pairs, p->arena->dev, psi, sigma, scale, st));
+        return B2X_OK;
+    }
+    for (int k = 0; k < kNumClasses; k++)
+        HIPCHK(launch_main(k, p->d_parts[k], p->d_items[k], p->n_items[k], p->arena->dev, psi, p->d_slabs, st));
+    HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma, scale, st));
+    return B2X_OK;
+}
+
+int b2x_plan_execute(b2x_plan *p, const double *psi, double *sigma, double scale, int on_device, void *stream) {
+    if (!p || !psi || !sigma)
+        return fail(B2X_ERR_INVALID, "b2x_plan_execute: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    if (on_device)
+        return run_plan(p, psi, sigma, scale, st);
+    if (!p->d_psi)
+        HIPCHK(hipMalloc((void **)&p->d_psi, (p->psi_len ? p->psi_len : 1) * sizeof(double)));
+    if (!p->d_sigma)
+        HIPCHK(hipMalloc((void **)&p->d_sigma, (p->sigma_len ? p->sigma_len : 1) * sizeof(double)));
+    HIPCHK(hipMemcpyAsync(p->d_psi, psi, p->psi_len * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(p->d_sigma, sigma, p->sigma_len * sizeof(double), hipMemcpyHostToDevice, st));
+    int rc = run_plan(p, p->d_psi, p->d_sigma, scale, st);
+    if (rc != B2X_OK)
+        return rc;
+    HIPCHK(hipMemcpyAsync(sigma, p->d_sigma, p->sigma_len * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return B2X_OK;
+}
+
+int b2x_plan_get_stats(const b2x_plan *p, b2x_plan_stats *st) {
+    if (!p || !st)
+        return fail(B2X_ERR_INVALID, "b2x_plan_get_stats: null argument");
+    *st = p->stats;
+    return B2X_OK;
+}
+
+int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, int n, void *stream,
+                         double *avg_ms_main, double *avg_ms_total) {
+    if (!p || !psi_dev || !sigma_dev || n <= 0)
+        return fail(B2X_ERR_INVALID, "b2x_plan_time_kernel: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t e0, e1, e2;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventCreate(&e2));
+    double tm = 0, tt = 0;
+    for (int i = 0; i < n; i++) {
+        float a = 0, b = 0;
+        if (p->fallback) {
+            HIPCHK(hipEventRecord(e0, st));
+            HIPCHK(launch_generic(p->d_pairs, p->n_pairs, p->arena->dev, psi_dev, sigma_dev, 1.0, st));
+            HIPCHK(hipEventRecord(e1, st));
+            HIPCHK(hipEventSynchronize(e1));
+            HIPCHK(hipEventElapsedTime(&a, e0, e1));
+            b = a;
+        } else {
+            // the dominant class is bracketed on its own; the rest + reduce make up the total
+            int d = p->dominant_cls;
+            HIPCHK(hipEventRecord(e0, st));
+            HIPCHK(launch_main(d, p->d_parts[d], p->d_items[d], p->n_items[d], p->arena->dev, psi_dev, p->d_slabs, st));
+            HIPCHK(hipEventRecord(e1, st));
+            for (int k = 0; k < kNumClasses; k++)
+                if (k != d)
+                    HIPCHK(launch_main(k, p->d_parts[k], p->d_items[k], p->n_items[k], p->arena->dev, psi_dev,
+                                       p->d_slabs, st));
+            HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma_dev, 1.0, st));
+            HIPCHK(hipEventRecord(e2, st));
+            HIPCHK(hipEventSynchronize(e2));
+            HIPCHK(hipEventElapsedTime(&a, e0, e1));
+            HIPCHK(hipEventElapsedTime(&b, e0, e2));
+        }
+        tm += a, tt += b;
+    }
+    (void)hipEventDestroy(e0), (void)hipEventDestroy(e1), (void)hipEventDestroy(e2);
+    if (avg_ms_main)
+        *avg_ms_main = tm / n;
+    if (avg_ms_total)
+        *avg_ms_total = tt / n;
+    return B2X_OK;
+}
+
+int b2x_plan_destroy(b2x_plan *p) {
+    if (p)
+        plan_free(p);
+    return B2X_OK;
+}
+
+// ---------------------------------------------------------------------------------- vectors
+static double *g_dot_partial = nullptr, *g_dot_out = nullptr;
+static int dot_scratch() {
+    if (!g_dot_partial) {
+        HIPCHK(hipMalloc((void **)&g_dot_partial, 64 * 256 * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&g_dot_out, 64 * sizeof(double)));
+    }
+    return B2X_OK;
+}
+
+int b2x_vec_multi_dot(const double *const *vs, int nv, const double *x, size_t n, double *host_result, void *stream) {
+    if (nv < 1 || nv > 64 || !vs || !x || !host_result)
+        return fail(B2X_ERR_INVALID, "b2x_vec_multi_dot: need 1 <= nv <= 64");
+    int rc = dot_scratch();
+    if (rc != B2X_OK)
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(launch_multidot(vs, nv, x, n, g_dot_partial, g_dot_out, st));
+    HIPCHK(hipMemcpyAsync(host_result, g_dot_out, nv * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return B2X_OK;
+}
+int b2x_vec_dot(const double *x, const double *y, size_t n, double *host_result, void *stream) {
+    const double *vs[1] = {x};
+    return b2x_vec_multi_dot(vs, 1, y, n, host_result, stream);
+}
+int b2x_vec_axpy(double a, const double *x, double *y, size_t n, void *stream) {
+    HIPCHK(launch_axpy(a, x, y, n, (hipStream_t)stream));
+    return B2X_OK;
+}
+int b2x_vec_scal(double a, double *x, size_t n, void *stream) {
+    HIPCHK(launch_scal(a, x, n, (hipStream_t)stream));
+    return B2X_OK;
+}
+int b2x_vec_copy(const double *x, double *y, size_t n, void *stream) {
+    HIPCHK(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return B2X_OK;
+}
+int b2x_vec_zero(double *x, size_t n, void *stream) {
+    HIPCHK(hipMemsetAsync(x, 0, n * sizeof(double), (hipStream_t)stream));
+    return B2X_OK;
+}
+int b2x_vec_precondition(double *q, const double *diag, double shift, size_t n, void *stream) {
+    HIPCHK(launch_precond(q, diag, shift, n, (hipStream_t)stream));
+    return B2X_OK;
+}
+int b2x_vec_lincomb(const double *const *vs, int nv, const double *coef, double *y, size_t n, void *stream) {
+    if (nv < 1 || nv > 64)
+        return fail(B2X_ERR_INVALID, "b2x_vec_lincomb: need 1 <= nv <= 64");
+    HIPCHK(launch_lincomb(vs, coef, nv, y, n, (hipStream_t)stream));
+    return B2X_OK;
+}
+
+// ---------------------------------------------------------------------------------- test hook
+// Compiles a plan and evaluates the compiled work list with plain host loops.  Exists so the
+// non-GPU test-suite can verify the PLAN COMPILER (segmentation into tiles/parts/items) against
+// the oracle; it is not declared in include/b2x.h and nothing in the product calls it.
+int b2x_debug_compile_and_emulate(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len,
+                                  uint64_t arena_len, const double *arena, const double *psi, double *sigma,
+                                  double scale, const b2x_plan_options *opt, b2x_plan_stats *stats, int *fallback) {
+    CompiledPlan cp;
+    std::string err;
+    int rc = compile_plan(n_pairs, pairs, psi_len, sigma_len, arena_len, opt, cp, err);
+    if (rc != B2X_OK)
+        return fail(rc, err);
+    if (stats)
+        *stats = cp.stats;
+    if (fallback)
+        *fallback = cp.fallback ? 1 : 0;
+    if (!cp.fallback && arena && psi && sigma)
+        emulate_plan_host(cp, arena, psi, sigma, scale);
+    return B2X_OK;
+}
+
+} // extern "C"

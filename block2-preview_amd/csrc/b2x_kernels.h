@@ -1,0 +1,22 @@
+// b2x_kernels.h — launch entry points of b2x_kernels.hip (internal; the public ABI is include/b2x.h)
+#pragma once
+#include "b2x_plan.hpp"
+#include <hip/hip_runtime_api.h>
+
+namespace b2x {
+
+hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t n_items, const double *arena,
+                       const double *psi, double *slabs, hipStream_t st);
+hipError_t launch_reduce(const DTile *tiles, uint32_t n_tiles, const double *slabs, double *sigma, double scale,
+                         hipStream_t st);
+hipError_t launch_generic(const b2x_pair *pairs, uint32_t n_pairs, const double *arena, const double *psi,
+                          double *sigma, double scale, hipStream_t st);
+hipError_t launch_axpy(double a, const double *x, double *y, size_t n, hipStream_t st);
+hipError_t launch_scal(double a, double *x, size_t n, hipStream_t st);
+hipError_t launch_precond(double *q, const double *diag, double shift, size_t n, hipStream_t st);
+hipError_t launch_lincomb(const double *const *vs, const double *coef, int nv, double *y, size_t n, hipStream_t st);
+int multidot_blocks(size_t n);
+hipError_t launch_multidot(const double *const *vs, int nv, const double *x, size_t n, double *partial, double *out,
+                           hipStream_t st);
+
+} // namespace b2x

@@ -1,0 +1,361 @@
+// b2x_kernels.hip — CDNA4 (gfx950) kernels of the H·psi plan replay.
+//
+// hpsi_main<NW, TMF, K1F>: one workgroup (NW waves) per work item.  A work item is a slice of the
+// part list of ONE output tile (TMF*16 rows x NW*16 columns of psi').  Wave w owns the 16-column
+// strip w of the tile and, for every part
+//     stage 0   W(k1c x 16)  = alpha * X(k1c x k0) * op(Y)(k0 x 16)      fp64 MFMA 16x16x4
+//     stage 1   V(mr  x 16) += op(Z)(mr x k1c) * W(k1c x 16)              fp64 MFMA 16x16x4
+// The stage-0 accumulator IS the stage-1 B operand: v_mfma_f64_16x16x4_f64 keeps C/D as
+// row = (lane>>4) + 4*reg, col = lane&15, and takes B as B[k = lane>>4][col = lane&15], so
+// register `reg` of a W fragment is exactly the B fragment of the k-step {4*reg + (lane>>4)}.
+// W therefore never leaves the register file (the reference round-trips it through a per-thread
+// work array, src/core/batch_gemm.hpp:1630-1635).  The A operands (X and op(Z) chunks, shared by all
+// strips of the tile) are staged through LDS with coalesced loads; op(Y) strips are private to a
+// wave and go straight from L2/HBM into registers.
+// Accumulators of an item are written to its partial slab; hpsi_reduce sums the slabs of each tile
+// in fixed order into psi' (psi' += scale * sum): no atomics, bitwise reproducible.
+#include "b2x_kernels.h"
+#include <hip/hip_runtime.h>
+
+namespace b2x {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+template <int NW, int TMF, int K1F>
+__global__ __launch_bounds__(NW * 64) void hpsi_main(const DPart *__restrict__ parts, const DItem *__restrict__ items,
+                                                       const double *__restrict__ arena,
+                                                       const double *__restrict__ psi, double *__restrict__ slabs) {
+    constexpr int NT = NW * 64, TM = TMF * 16, K1C = K1F * 16;
+    constexpr int LDX = 18;                              // Xs[row][k], 18 == 2 mod 32 doubles: conflict-free b64 reads
+    constexpr int LDZT = (TM % 32 == 0) ? TM + 16 : TM;  // Zs[k][row] layout for transposed Z, == 16 mod 32
+    constexpr int ZS_N = TM * LDX, ZS_T = 16 * LDZT;
+    constexpr int ZS = ZS_N > ZS_T ? ZS_N : ZS_T;
+    __shared__ double lds[K1C * LDX + ZS];
+    double *Xs = lds, *Zs = lds + K1C * LDX;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const DItem item = items[blockIdx.x];
+
+    v4d acc[TMF];
+#pragma unroll
+    for (int f = 0; f < TMF; f++)
+        acc[f] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    for (uint32_t pi = item.part_begin; pi < item.part_end; pi++) {
+        const DPart P = parts[pi];
+        const int k0 = P.k0, mr = P.mr, nc = P.nc, tr0 = P.tr0, tc0 = P.tc0;
+        const int cabs = wave * 16 + c;
+        const bool col_ok = cabs >= tc0 && cabs < tc0 + nc;
+        const bool wave_on = (wave * 16 + 16 > tc0) && (wave * 16 < tc0 + nc);
+        const double *yp = arena + P.y_off + (int64_t)(cabs - tc0) * P.scy;
+        const int f_lo = tr0 >> 4, f_hi = (tr0 + mr + 15) >> 4; // row fragments touched by this part
+        const bool zt = (P.srz == 1 && P.skz != 1);             // op(Z) stored k-major (transposed block)
+        const int lsr = zt ? 1 : LDX, lsk = zt ? LDZT : 1;
+
+        for (int k1lo = 0; k1lo < P.k1; k1lo += K1C) {
+            const int k1c = min(K1C, P.k1 - k1lo);
+            const double *xp = psi + P.x_off + (int64_t)k1lo * P.ldx;
+            const double *zp = arena + P.z_off + (int64_t)k1lo * P.skz;
+
+            v4d w[K1F];
+#pragma unroll
+            for (int f = 0; f < K1F; f++)
+                w[f] = v4d{0.0, 0.0, 0.0, 0.0};
+
+            // ---------------- stage 0: W = X * op(Y), k0 in chunks of 16 ---------------------
+            for (int kb = 0; kb < k0; kb += 16) {
+                __syncthreads(); // readers of the previous Xs / Zs chunk are done
+                for (int idx = tid; idx < K1C * 16; idx += NT) {
+                    int row = idx >> 4, kk = idx & 15;
+                    double v = 0.0;
+                    if (row < k1c && kb + kk < k0)
+                        v = xp[(int64_t)row * P.ldx + kb + kk];
+                    Xs[row * LDX + kk] = v;
+                }
+                double b[4];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    int k = kb + 4 * s + g;
+                    b[s] = (col_ok && k < k0) ? yp[(int64_t)k * P.sky] : 0.0;
+                }
+                __syncthreads();
+                if (wave_on) {
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+#pragma unroll
+                        for (int f = 0; f < K1F; f++)
+                            if (f * 16 < k1c) {
+                                double a = Xs[(f * 16 + c) * LDX + 4 * s + g];
+                                w[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s], w[f], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+#pragma unroll
+            for (int f = 0; f < K1F; f++)
+                w[f] *= P.alpha;
+
+            // ---------------- stage 1: V += op(Z) * W, k1c in chunks of 16 -------------------
+#pragma unroll
+            for (int f1 = 0; f1 < K1F; f1++) {
+                if (f1 * 16 < k1c) {
+                    const int kc = f1 * 16;
+                    __syncthreads();
+                    const int r_lo = f_lo * 16, n_rows = (f_hi - f_lo) * 16;
+                    if (!zt) {
+                        for (int idx = tid; idx < n_rows * 16; idx += NT) {
+                            int row = r_lo + (idx >> 4), kk = idx & 15;
+                            int rr = row - tr0;
+                            double v = 0.0;
+                            if (rr >= 0 && rr < mr && kc + kk < k1c)
+                                v = zp[(int64_t)rr * P.srz + (int64_t)(kc + kk) * P.skz];
+                            Zs[row * LDX + kk] = v;
+                        }
+                    } else {
+                        for (int idx = tid; idx < n_rows * 16; idx += NT) {
+                            int kk = idx / n_rows, row = r_lo + idx % n_rows;
+                            int rr = row - tr0;
+                            double v = 0.0;
+                            if (rr >= 0 && rr < mr && kc + kk < k1c)
+                                v = zp[(int64_t)rr + (int64_t)(kc + kk) * P.skz];
+                            Zs[kk * LDZT + row] = v;
+                        }
+                    }
+                    __syncthreads();
+                    if (wave_on) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const double bw = w[f1][r];
+#pragma unroll
+                            for (int f = 0; f < TMF; f++)
+                                if (f >= f_lo && f < f_hi) {
+                                    double a = Zs[(f * 16 + c) * lsr + (4 * r + g) * lsk];
+                                    acc[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bw, acc[f], 0, 0, 0);
+                                }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---------------- epilogue: accumulators -> partial slab ----------------------------------
+    double *slab = slabs + item.slab_off;
+    const int col = wave * 16 + c;
+    if (col < item.cols) {
+#pragma unroll
+        for (int f = 0; f < TMF; f++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int row = f * 16 + 4 * r + g;
+                if (row < item.rows)
+                    slab[(int64_t)row * item.cols + col] = acc[f][r];
+            }
+    }
+}
+
+// psi'[tile] += scale * sum_i slab_i[tile]   (fixed order i = 0..n_items-1)
+__global__ __launch_bounds__(256) void hpsi_reduce(const DTile *__restrict__ tiles, const double *__restrict__ slabs,
+                                                    double *__restrict__ sigma, double scale) {
+    const DTile t = tiles[blockIdx.x];
+    const int n = t.rows * t.cols;
+    if (t.n_items == 0)
+        return;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const double *s = slabs + t.slab_off + e;
+        double sum = 0.0;
+        for (int i = 0; i < t.n_items; i++)
+            sum += s[(int64_t)i * n];
+        int r = e / t.cols, cc = e - r * t.cols;
+        sigma[t.sigma_off + (int64_t)r * t.ld + cc] += scale * sum;
+    }
+}
+
+// ------------- generic fallback / on-device cross-check (any plan; atomics, not reproducible) -----
+// one workgroup per pair: W chunk (16 rows of W at a time) in LDS, scalar FMAs, atomicAdd into psi'.
+__global__ __launch_bounds__(256) void hpsi_generic(const b2x_pair *__restrict__ pairs, const double *__restrict__ arena,
+                                                     const double *__restrict__ psi, double *__restrict__ sigma,
+                                                     double scale) {
+    const b2x_pair p = pairs[blockIdx.x];
+    constexpr int WC = 2048; // doubles of W kept in LDS per chunk
+    __shared__ double Ws[WC];
+    const int n = p.n0;
+    const int rows_per = max(1, WC / n) < p.m0 ? max(1, WC / n) : p.m0;
+    const double *X = psi + p.x_off, *Y = arena + p.y_off, *Z = arena + p.z_off;
+    double *V = sigma + p.v_off;
+    // n may exceed WC: then process column chunks too
+    for (int cb = 0; cb < n; cb += WC) {
+        const int ncol = min(WC, n - cb);
+        const int rp = max(1, WC / ncol) < p.m0 ? max(1, WC / ncol) : p.m0;
+        for (int rb = 0; rb < p.m0; rb += rp) {
+            const int nr = min(rp, p.m0 - rb);
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < nr * ncol; idx += 256) {
+                int r = idx / ncol, cidx = idx - r * ncol + cb;
+                double s = 0.0;
+                for (int k = 0; k < p.k0; k++) {
+                    double y = p.tb0 ? Y[(int64_t)cidx * p.ldb0 + k] : Y[(int64_t)k * p.ldb0 + cidx];
+                    s += X[(int64_t)(rb + r) * p.lda0 + k] * y;
+                }
+                Ws[r * ncol + (cidx - cb)] = s * p.alpha0;
+            }
+            __syncthreads();
+            for (int idx = threadIdx.x; idx < p.m1 * ncol; idx += 256) {
+                int i = idx / ncol, cidx = idx - i * ncol;
+                double s = 0.0;
+                for (int r = 0; r < nr; r++) {
+                    double z = p.ta1 ? Z[(int64_t)(rb + r) * p.lda1 + i] : Z[(int64_t)i * p.lda1 + rb + r];
+                    s += z * Ws[r * ncol + cidx];
+                }
+                atomicAdd(&V[(int64_t)i * p.ldc1 + cb + cidx], s * p.alpha1 * scale);
+            }
+        }
+    }
+    (void)rows_per;
+}
+
+// ------------------------------------ vector kernels ------------------------------------------
+__global__ void vec_axpy_k(double a, const double *x, double *y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] += a * x[i];
+}
+__global__ void vec_scal_k(double a, double *x, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] *= a;
+}
+__global__ void vec_precond_k(double *q, const double *diag, double shift, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double d = diag[i] - shift;
+        if (fabs(d) > 1e-12)
+            q[i] /= d;
+    }
+}
+struct VecPtrs {
+    const double *p[64];
+    double coef[64];
+};
+// y = sum_j coef[j] * vs[j]
+__global__ void vec_lincomb_k(VecPtrs vp, int nv, double *y, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int j = 0; j < nv; j++)
+            s += vp.coef[j] * vp.p[j][i];
+        y[i] = s;
+    }
+}
+// partial[j * nblk + b] = sum over block b's grid-stride share of vs[j][i] * x[i]; fixed-order two-pass
+__global__ __launch_bounds__(256) void vec_multidot_k(VecPtrs vp, int nv, const double *x, size_t n, double *partial) {
+    __shared__ double sh[256];
+    for (int j = 0; j < nv; j++) {
+        double s = 0.0;
+        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+            s += vp.p[j][i] * x[i];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o)
+                sh[threadIdx.x] += sh[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0)
+            partial[(size_t)j * gridDim.x + blockIdx.x] = sh[0];
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void vec_multidot_final_k(const double *partial, int nblk, double *out) {
+    __shared__ double sh[256];
+    int j = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += 256)
+        s += partial[(size_t)j * nblk + b];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        out[j] = sh[0];
+}
+
+// ------------------------------------ launchers -----------------------------------------------
+template <int NW, int TMF, int K1F>
+static hipError_t launch_main_t(const DPart *parts, const DItem *items, uint32_t n_items, const double *arena,
+                                const double *psi, double *slabs, hipStream_t st) {
+    if (n_items == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL((hpsi_main<NW, TMF, K1F>), dim3(n_items), dim3(NW * 64), 0, st, parts, items, arena, psi, slabs);
+    return hipGetLastError();
+}
+
+hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t n_items, const double *arena,
+                       const double *psi, double *slabs, hipStream_t st) {
+    switch (cls) {
+    case 0:
+        return launch_main_t<1, 2, 2>(parts, items, n_items, arena, psi, slabs, st);
+    case 1:
+        return launch_main_t<2, 4, 4>(parts, items, n_items, arena, psi, slabs, st);
+    case 2:
+        return launch_main_t<4, 8, 4>(parts, items, n_items, arena, psi, slabs, st);
+    case 3:
+        return launch_main_t<8, 16, 8>(parts, items, n_items, arena, psi, slabs, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_reduce(const DTile *tiles, uint32_t n_tiles, const double *slabs, double *sigma, double scale,
+                         hipStream_t st) {
+    if (n_tiles == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(hpsi_reduce, dim3(n_tiles), dim3(256), 0, st, tiles, slabs, sigma, scale);
+    return hipGetLastError();
+}
+
+hipError_t launch_generic(const b2x_pair *pairs, uint32_t n_pairs, const double *arena, const double *psi,
+                          double *sigma, double scale, hipStream_t st) {
+    if (n_pairs == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(hpsi_generic, dim3(n_pairs), dim3(256), 0, st, pairs, arena, psi, sigma, scale);
+    return hipGetLastError();
+}
+
+static inline int vec_grid(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+}
+hipError_t launch_axpy(double a, const double *x, double *y, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(vec_axpy_k, dim3(vec_grid(n)), dim3(256), 0, st, a, x, y, n);
+    return hipGetLastError();
+}
+hipError_t launch_scal(double a, double *x, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(vec_scal_k, dim3(vec_grid(n)), dim3(256), 0, st, a, x, n);
+    return hipGetLastError();
+}
+hipError_t launch_precond(double *q, const double *diag, double shift, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(vec_precond_k, dim3(vec_grid(n)), dim3(256), 0, st, q, diag, shift, n);
+    return hipGetLastError();
+}
+hipError_t launch_lincomb(const double *const *vs, const double *coef, int nv, double *y, size_t n, hipStream_t st) {
+    VecPtrs vp;
+    for (int j = 0; j < nv; j++)
+        vp.p[j] = vs[j], vp.coef[j] = coef[j];
+    hipLaunchKernelGGL(vec_lincomb_k, dim3(vec_grid(n)), dim3(256), 0, st, vp, nv, y, n);
+    return hipGetLastError();
+}
+int multidot_blocks(size_t n) {
+    size_t b = (n + 256 * 8 - 1) / (256 * 8);
+    return (int)(b < 1 ? 1 : (b > 256 ? 256 : b));
+}
+hipError_t launch_multidot(const double *const *vs, int nv, const double *x, size_t n, double *partial, double *out,
+                           hipStream_t st) {
+    VecPtrs vp;
+    for (int j = 0; j < nv; j++)
+        vp.p[j] = vs[j], vp.coef[j] = 0.0;
+    int nb = multidot_blocks(n);
+    hipLaunchKernelGGL(vec_multidot_k, dim3(nb), dim3(256), 0, st, vp, nv, x, n, partial);
+    hipLaunchKernelGGL(vec_multidot_final_k, dim3(nv), dim3(256), 0, st, partial, nb, out);
+    return hipGetLastError();
+}
+
+} // namespace b2x

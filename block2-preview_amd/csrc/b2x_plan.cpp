@@ -1,0 +1,338 @@
+// b2x_plan.cpp — plan compiler (host).  See b2x_plan.hpp for the scheme.
+#include "b2x_plan.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+namespace b2x {
+
+namespace {
+
+struct Window {
+    uint64_t off;
+    int32_t m, n, ld;
+    uint32_t pair;
+};
+
+struct Component {
+    uint64_t base; // psi' offset of local (0, 0)
+    int32_t ld, rows, cols;
+    uint32_t w_begin, w_end; // windows (sorted array) of this component
+};
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
+
+// cut `total` into n nearly equal pieces that are multiples of 16 (except the last)
+std::vector<int> balanced_cuts(int total, int max_piece) {
+    int n = ceil_div(total, max_piece);
+    int piece = round_up(ceil_div(total, n), 16);
+    if (piece > max_piece)
+        piece = max_piece;
+    std::vector<int> cuts;
+    for (int s = 0; s < total; s += piece)
+        cuts.push_back(s);
+    cuts.push_back(total);
+    return cuts;
+}
+
+} // namespace
+
+int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len, uint64_t arena_len,
+                 const b2x_plan_options *opt, CompiledPlan &out, std::string &err) {
+    out = CompiledPlan();
+    b2x_plan_stats &st = out.stats;
+    st.n_pairs = n_pairs, st.psi_len = psi_len, st.sigma_len = sigma_len;
+    // ---- validation + statistics -------------------------------------------------------------
+    std::vector<std::pair<uint64_t, uint64_t>> opext;
+    opext.reserve(2 * n_pairs);
+    for (size_t i = 0; i < n_pairs; i++) {
+        const b2x_pair &p = pairs[i];
+        if (p.ta0 != 0 || p.tb1 != 0 || p.tb0 > 1 || p.ta1 > 1) {
+            err = "pair " + std::to_string(i) + ": unsupported transpose flags (this path has ta0 = tb1 = 0)";
+            return B2X_ERR_INVALID;
+        }
+        if (p.m0 <= 0 || p.n0 <= 0 || p.k0 <= 0 || p.m1 <= 0 || p.k1 != p.m0 || p.n1 != p.n0) {
+            err = "pair " + std::to_string(i) + ": inconsistent dimensions (need k1 == m0, n1 == n0, all > 0)";
+            return B2X_ERR_INVALID;
+        }
+        if (p.lda0 < p.k0 || p.ldb0 < (p.tb0 ? p.k0 : p.n0) || p.lda1 < (p.ta1 ? p.m1 : p.k1) || p.ldc1 < p.n1) {
+            err = "pair " + std::to_string(i) + ": leading dimension smaller than row length";
+            return B2X_ERR_INVALID;
+        }
+        uint64_t ex = (uint64_t)(p.m0 - 1) * p.lda0 + p.k0;
+        uint64_t ey = p.tb0 ? (uint64_t)(p.n0 - 1) * p.ldb0 + p.k0 : (uint64_t)(p.k0 - 1) * p.ldb0 + p.n0;
+        uint64_t ez = p.ta1 ? (uint64_t)(p.k1 - 1) * p.lda1 + p.m1 : (uint64_t)(p.m1 - 1) * p.lda1 + p.k1;
+        uint64_t ev = (uint64_t)(p.m1 - 1) * p.ldc1 + p.n1;
+        if (p.x_off + ex > psi_len || p.v_off + ev > sigma_len || p.y_off + ey > arena_len ||
+            p.z_off + ez > arena_len) {
+            err = "pair " + std::to_string(i) + ": operand runs past the end of psi / psi' / arena";
+            return B2X_ERR_INVALID;
+        }
+        st.macs += (uint64_t)p.m0 * p.n0 * p.k0 + (uint64_t)p.m1 * p.n1 * p.k1;
+        opext.emplace_back(p.y_off, ey);
+        opext.emplace_back(p.z_off, ez);
+    }
+    std::sort(opext.begin(), opext.end());
+    {
+        uint64_t cur_b = 0, cur_e = 0;
+        for (auto &e : opext) {
+            if (e.first >= cur_e) {
+                st.op_elems_unique += cur_e - cur_b;
+                cur_b = e.first, cur_e = e.first + e.second;
+            } else
+                cur_e = std::max(cur_e, e.first + e.second);
+        }
+        st.op_elems_unique += cur_e - cur_b;
+    }
+    if (n_pairs == 0)
+        return B2X_OK;
+    // ---- output windows -> disjoint components -----------------------------------------------
+    std::vector<Window> win(n_pairs);
+    for (size_t i = 0; i < n_pairs; i++)
+        win[i] = Window{pairs[i].v_off, pairs[i].m1, pairs[i].n1, pairs[i].ldc1, (uint32_t)i};
+    std::stable_sort(win.begin(), win.end(), [](const Window &a, const Window &b) { return a.off < b.off; });
+    std::vector<Component> comps;
+    {
+        size_t i = 0;
+        while (i < win.size()) {
+            uint64_t end = win[i].off + (uint64_t)(win[i].m - 1) * win[i].ld + win[i].n;
+            size_t j = i + 1;
+            while (j < win.size() && win[j].off < end) {
+                end = std::max(end, win[j].off + (uint64_t)(win[j].m - 1) * win[j].ld + win[j].n);
+                j++;
+            }
+            Component c;
+            c.base = win[i].off, c.w_begin = (uint32_t)i, c.w_end = (uint32_t)j;
+            // a single-row window may carry any ld; take ld from a multi-row window if there is one
+            int ld = 0;
+            for (size_t k = i; k < j; k++)
+                if (win[k].m > 1) {
+                    if (ld == 0)
+                        ld = win[k].ld;
+                    else if (ld != win[k].ld) {
+                        out.fallback = true;
+                        out.fallback_reason = "overlapping output windows with different leading dimensions";
+                    }
+                }
+            if (ld == 0) {
+                ld = 1;
+                for (size_t k = i; k < j; k++)
+                    ld = std::max(ld, (int)(win[k].off - c.base) + win[k].n);
+            }
+            c.ld = ld, c.rows = 0, c.cols = 0;
+            // column alignment: find shift c0 so that no window wraps around a row
+            int c0 = 0;
+            for (int attempt = 0; attempt < 2 && !out.fallback; attempt++) {
+                bool ok = true;
+                for (size_t k = i; k < j && ok; k++) {
+                    uint64_t rel = win[k].off - c.base + (uint64_t)c0;
+                    if ((int)(rel % (uint64_t)ld) + win[k].n > ld)
+                        ok = false, c0 = (int)((uint64_t)ld - (win[k].off - c.base) % (uint64_t)ld) % ld;
+                }
+                if (ok)
+                    break;
+                if (attempt == 1) {
+                    out.fallback = true;
+                    out.fallback_reason = "output windows do not share a row alignment";
+                }
+            }
+            if ((uint64_t)c0 > c.base) {
+                out.fallback = true;
+                out.fallback_reason = "output window alignment precedes psi'";
+            }
+            if (!out.fallback) {
+                c.base -= (uint64_t)c0;
+                for (size_t k = i; k < j; k++) {
+                    uint64_t rel = win[k].off - c.base;
+                    c.rows = std::max(c.rows, (int)(rel / (uint64_t)ld) + win[k].m);
+                    c.cols = std::max(c.cols, (int)(rel % (uint64_t)ld) + win[k].n);
+                }
+            }
+            comps.push_back(c);
+            i = j;
+        }
+    }
+    st.n_targets = comps.size();
+    if (out.fallback)
+        return B2X_OK;
+    // ---- tiles, parts, items -----------------------------------------------------------------
+    struct HostTile {
+        int cls;
+        std::vector<DPart> parts;
+        std::vector<double> cost;
+    };
+    int64_t total_cost = 0;
+    uint64_t cls_macs[kNumClasses] = {0, 0, 0, 0};
+    std::vector<HostTile> htiles;
+    for (const Component &c : comps) {
+        // class by shape: columns decide the number of waves, rows the fragment count
+        int cls;
+        if (opt && opt->tile_n > 0) {
+            cls = kNumClasses - 1;
+            for (int k = 0; k < kNumClasses; k++)
+                if (kClasses[k].nw * 16 >= opt->tile_n) {
+                    cls = k;
+                    break;
+                }
+        } else {
+            if (c.cols <= 16 && c.rows <= 32)
+                cls = 0;
+            else if (c.cols <= 32 && c.rows <= 64)
+                cls = 1;
+            else if (c.cols <= 96 && c.rows <= 160)
+                cls = 2;
+            else
+                cls = 3;
+        }
+        const KClass &K = kClasses[cls];
+        const int TM = K.tmf * 16, TN = K.nw * 16, K1C = K.k1f * 16;
+        std::vector<int> rc = balanced_cuts(c.rows, TM), cc = balanced_cuts(c.cols, TN);
+        int nrt = (int)rc.size() - 1, nct = (int)cc.size() - 1;
+        size_t t0 = htiles.size();
+        htiles.resize(t0 + (size_t)nrt * nct);
+        for (int a = 0; a < nrt; a++)
+            for (int b = 0; b < nct; b++) {
+                DTile t{};
+                t.sigma_off = c.base + (uint64_t)rc[a] * c.ld + cc[b];
+                t.ld = c.ld, t.rows = rc[a + 1] - rc[a], t.cols = cc[b + 1] - cc[b];
+                out.tiles.push_back(t);
+                htiles[t0 + (size_t)a * nct + b].cls = cls;
+            }
+        for (uint32_t wi = c.w_begin; wi < c.w_end; wi++) {
+            const Window &w = win[wi];
+            const b2x_pair &p = pairs[w.pair];
+            uint64_t rel = w.off - c.base;
+            int row0 = (int)(rel / (uint64_t)c.ld), col0 = (int)(rel % (uint64_t)c.ld);
+            int a0 = (int)(std::upper_bound(rc.begin(), rc.end(), row0) - rc.begin()) - 1;
+            int b0 = (int)(std::upper_bound(cc.begin(), cc.end(), col0) - cc.begin()) - 1;
+            for (int a = a0; a < nrt && rc[a] < row0 + w.m; a++)
+                for (int b = b0; b < nct && cc[b] < col0 + w.n; b++) {
+                    int ra = std::max(row0, rc[a]), rb = std::min(row0 + w.m, rc[a + 1]);
+                    int ca = std::max(col0, cc[b]), cb = std::min(col0 + w.n, cc[b + 1]);
+                    HostTile &ht = htiles[t0 + (size_t)a * nct + b];
+                    {
+                        DPart d{};
+                        int r_lo = ra - row0, c_lo = ca - col0;
+                        d.x_off = p.x_off;
+                        d.ldx = p.lda0;
+                        if (p.tb0) // op(Y)[k][c] = Y[c][k]
+                            d.y_off = p.y_off + (uint64_t)c_lo * p.ldb0, d.sky = 1, d.scy = p.ldb0;
+                        else
+                            d.y_off = p.y_off + (uint64_t)c_lo, d.sky = p.ldb0, d.scy = 1;
+                        if (p.ta1) // op(Z)[r][k] = Z[k][r]
+                            d.z_off = p.z_off + (uint64_t)r_lo, d.srz = 1, d.skz = p.lda1;
+                        else
+                            d.z_off = p.z_off + (uint64_t)r_lo * p.lda1, d.srz = p.lda1, d.skz = 1;
+                        d.alpha = p.alpha0 * p.alpha1;
+                        d.k0 = p.k0, d.k1 = p.k1;
+                        d.mr = (int16_t)(rb - ra), d.nc = (int16_t)(cb - ca);
+                        d.tr0 = (int16_t)(ra - rc[a]), d.tc0 = (int16_t)(ca - cc[b]);
+                        // cost model: MFMA issue slots (16x16x4 granules) of both stages
+                        double c0 = (double)round_up(p.k1, 16) * round_up(d.nc, 16) * round_up(p.k0, 4);
+                        double c1 = (double)round_up(d.mr, 16) * round_up(d.nc, 16) * round_up(p.k1, 4);
+                        double cst = c0 + c1 + 4096.0 * ceil_div(p.k1, K1C);
+                        ht.parts.push_back(d);
+                        ht.cost.push_back(cst);
+                        total_cost += (int64_t)cst;
+                        cls_macs[cls] += (uint64_t)p.k1 * d.nc * p.k0 + (uint64_t)d.mr * d.nc * p.k1;
+                    }
+                }
+        }
+    }
+    st.n_tiles = out.tiles.size();
+    // work-item size: aim for ~16 items per CU, but never below ~0.5 MMAC-equivalents
+    double item_cost = opt && opt->item_macs > 0 ? (double)opt->item_macs : std::max((double)total_cost / 4096.0, 524288.0);
+    uint64_t slab = 0;
+    for (size_t t = 0; t < htiles.size(); t++) {
+        HostTile &ht = htiles[t];
+        DTile &dt = out.tiles[t];
+        ClassWork &cw = out.cls[ht.cls];
+        dt.slab_off = slab;
+        dt.n_items = 0;
+        if (ht.parts.empty())
+            continue;
+        double tile_cost = std::accumulate(ht.cost.begin(), ht.cost.end(), 0.0);
+        int n_it = std::max(1, (int)std::lround(tile_cost / item_cost));
+        double per = tile_cost / n_it, acc = 0;
+        uint32_t pb = (uint32_t)cw.parts.size(), begin = pb;
+        int made = 0;
+        for (size_t k = 0; k < ht.parts.size(); k++) {
+            cw.parts.push_back(ht.parts[k]);
+            acc += ht.cost[k];
+            bool last = k + 1 == ht.parts.size();
+            if (last || (acc >= per * (made + 1) && made + 1 < n_it)) {
+                DItem it{};
+                it.part_begin = begin, it.part_end = (uint32_t)cw.parts.size();
+                it.slab_off = slab, it.rows = dt.rows, it.cols = dt.cols;
+                cw.items.push_back(it);
+                slab += (uint64_t)dt.rows * dt.cols;
+                begin = it.part_end;
+                made++;
+            }
+        }
+        dt.n_items = made;
+        st.n_parts += ht.parts.size();
+        std::vector<DPart>().swap(ht.parts);
+    }
+    out.slab_elems = slab;
+    // longest items first (tail balance); stable so equal items keep plan order
+    for (int k = 0; k < kNumClasses; k++) {
+        ClassWork &cw = out.cls[k];
+        std::stable_sort(cw.items.begin(), cw.items.end(), [](const DItem &a, const DItem &b) {
+            return (a.part_end - a.part_begin) > (b.part_end - b.part_begin);
+        });
+        st.n_items += cw.items.size();
+    }
+    for (int k = 0; k < kNumClasses; k++) {
+        out.cls_macs[k] = cls_macs[k];
+        if (cls_macs[k] > cls_macs[st.dominant_class])
+            st.dominant_class = k;
+    }
+    st.macs_executed = cls_macs[0] + cls_macs[1] + cls_macs[2] + cls_macs[3];
+    st.macs_dominant = cls_macs[st.dominant_class];
+    st.device_bytes = slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
+    return B2X_OK;
+}
+
+void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double *psi, double *sigma, double scale) {
+    std::vector<double> slabs(cp.slab_elems, 0.0);
+    for (int k = 0; k < kNumClasses; k++) {
+        const ClassWork &cw = cp.cls[k];
+        const int TN = kClasses[k].nw * 16;
+        for (const DItem &it : cw.items) {
+            double *acc = slabs.data() + it.slab_off;
+            for (uint32_t pi = it.part_begin; pi < it.part_end; pi++) {
+                const DPart &P = cw.parts[pi];
+                std::vector<double> w((size_t)P.k1 * P.nc);
+                for (int r = 0; r < P.k1; r++)
+                    for (int c = 0; c < P.nc; c++) {
+                        double s = 0;
+                        for (int k2 = 0; k2 < P.k0; k2++)
+                            s += psi[P.x_off + (uint64_t)r * P.ldx + k2] *
+                                 arena[P.y_off + (uint64_t)k2 * P.sky + (uint64_t)c * P.scy];
+                        w[(size_t)r * P.nc + c] = s * P.alpha;
+                    }
+                for (int r = 0; r < P.mr; r++)
+                    for (int c = 0; c < P.nc; c++) {
+                        double s = 0;
+                        for (int k2 = 0; k2 < P.k1; k2++)
+                            s += arena[P.z_off + (uint64_t)r * P.srz + (uint64_t)k2 * P.skz] * w[(size_t)k2 * P.nc + c];
+                        acc[(size_t)(P.tr0 + r) * it.cols + P.tc0 + c] += s;
+                    }
+            }
+            (void)TN;
+        }
+    }
+    for (const DTile &t : cp.tiles)
+        for (int r = 0; r < t.rows; r++)
+            for (int c = 0; c < t.cols; c++) {
+                double s = 0;
+                for (int i = 0; i < t.n_items; i++)
+                    s += slabs[t.slab_off + (uint64_t)i * t.rows * t.cols + (uint64_t)r * t.cols + c];
+                sigma[t.sigma_off + (uint64_t)r * t.ld + c] += scale * s;
+            }
+}
+
+} // namespace b2x

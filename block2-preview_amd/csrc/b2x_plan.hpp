@@ -1,0 +1,79 @@
+// b2x_plan.hpp — host-side compiler from the reference's GEMM-pair list to the device work list.
+//
+// The reference replays pairs one by one with thread-private copies of psi' and a tree reduction
+// (BatchGEMMSeq::operator(), src/core/batch_gemm.hpp:1606-1682).  On MI355X the list is instead
+// re-segmented by OUTPUT: psi' is cut into tiles, every pair is split into the parts that touch a
+// tile, each tile's part list is chopped into work items of similar cost, and one workgroup per
+// item accumulates its parts in registers and writes a partial slab; a second kernel sums the
+// slabs of a tile in fixed order into psi'.  No atomics, bitwise reproducible.
+#pragma once
+#include "../../include/b2x.h"
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace b2x {
+
+// One (pair x tile) part.  Everything the kernel needs, 72 bytes.
+struct DPart {
+    uint64_t x_off; // psi   offset of X[k1lo][0]
+    uint64_t y_off; // arena offset of op(Y)[0][c_lo]
+    uint64_t z_off; // arena offset of op(Z)[r_lo][k1lo]
+    double alpha;   // alpha0 * alpha1
+    int32_t ldx;    // X leading dimension
+    int32_t sky, scy; // op(Y)[k][c] = Y[k*sky + c*scy]
+    int32_t srz, skz; // op(Z)[r][k] = Z[r*srz + k*skz]
+    int32_t k0;       // stage-0 inner dimension
+    int32_t k1;       // rows of X = inner dimension of stage 1 (the kernel walks it in chunks of 16*K1F)
+    int16_t mr, nc;   // output rows / cols of this part
+    int16_t tr0, tc0; // offset of the part's output window inside the tile
+};
+static_assert(sizeof(DPart) == 72, "DPart layout");
+
+struct DItem {
+    uint32_t part_begin, part_end;
+    uint64_t slab_off; // element offset of this item's partial slab
+    int32_t rows, cols; // tile dims (slab is rows x cols, ld = cols)
+};
+static_assert(sizeof(DItem) == 24, "DItem layout");
+
+struct DTile {
+    uint64_t sigma_off; // psi' offset of the tile's top-left element
+    uint64_t slab_off;  // first slab of this tile; slabs of the tile are consecutive
+    int32_t ld;         // psi' leading dimension of the enclosing sector
+    int32_t rows, cols;
+    int32_t n_items;
+};
+static_assert(sizeof(DTile) == 32, "DTile layout");
+
+// kernel classes: NW waves (16 output columns each), TMF row fragments, K1F k1 fragments
+struct KClass {
+    int nw, tmf, k1f;
+};
+static const KClass kClasses[] = {{1, 2, 2}, {2, 4, 4}, {4, 8, 4}, {8, 16, 8}};
+static const int kNumClasses = 4;
+
+struct ClassWork {
+    std::vector<DPart> parts;
+    std::vector<DItem> items;
+};
+
+struct CompiledPlan {
+    ClassWork cls[kNumClasses];
+    std::vector<DTile> tiles;
+    uint64_t slab_elems = 0;
+    uint64_t cls_macs[kNumClasses] = {0, 0, 0, 0}; // MACs the kernels of each class execute
+    b2x_plan_stats stats{};
+    bool fallback = false; // windows could not be segmented -> generic atomic kernel
+    std::string fallback_reason;
+};
+
+// returns 0 / B2X_ERR_INVALID (err filled)
+int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len, uint64_t arena_len,
+                 const b2x_plan_options *opt, CompiledPlan &out, std::string &err);
+
+// Host emulation of exactly what the device kernels compute from a CompiledPlan (plain loops, no
+// MFMA).  TEST HOOK for the plan compiler only — never reachable from b2x_plan_execute.
+void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double *psi, double *sigma, double scale);
+
+} // namespace b2x

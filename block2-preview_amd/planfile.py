@@ -1,0 +1,98 @@
+"""Reader/writer for the B2XPLAN1 container (layout: oracle/planfile.h) and the numpy view of
+``b2x_pair`` (include/b2x.h).  Pure data plumbing — no arithmetic lives here."""
+import numpy as np
+
+PAIR_DTYPE = np.dtype(
+    [
+        ("m0", "<i4"), ("n0", "<i4"), ("k0", "<i4"),
+        ("lda0", "<i4"), ("ldb0", "<i4"),
+        ("m1", "<i4"), ("n1", "<i4"), ("k1", "<i4"),
+        ("lda1", "<i4"), ("ldc1", "<i4"),
+        ("ta0", "u1"), ("tb0", "u1"), ("ta1", "u1"), ("tb1", "u1"),
+        ("reserved", "<u4"),
+        ("alpha0", "<f8"), ("alpha1", "<f8"),
+        ("x_off", "<u8"), ("y_off", "<u8"), ("z_off", "<u8"), ("v_off", "<u8"),
+    ],
+    align=False,
+)
+assert PAIR_DTYPE.itemsize == 96
+
+F_ARENA, F_PSI, F_SIGMA, F_DIAG, F_PSIOUT = 1, 2, 4, 8, 16
+
+
+class PlanFile:
+    """In-memory image of one plan file."""
+
+    def __init__(self):
+        self.pairs = np.zeros(0, PAIR_DTYPE)
+        self.psi_len = self.sigma_len = self.max_work = self.arena_len = 0
+        self.ranges = np.zeros((0, 2), np.uint64)
+        self.meta = np.zeros(0)
+        self.arena = self.psi = self.sigma_ref = self.diag = self.psi_out = None
+
+    @property
+    def n_pairs(self):
+        return len(self.pairs)
+
+    @property
+    def macs(self):
+        p = self.pairs
+        return int(
+            (p["m0"].astype(np.int64) * p["n0"] * p["k0"]).sum()
+            + (p["m1"].astype(np.int64) * p["n1"] * p["k1"]).sum()
+        )
+
+
+def read_plan(fn):
+    with open(fn, "rb") as f:
+        raw = f.read()
+    if raw[:8] != b"B2XPLAN1":
+        raise ValueError("%s: not a B2XPLAN1 file" % fn)
+    hdr = np.frombuffer(raw, "<u8", 8, 8)
+    n_pairs, psi_len, sigma_len, max_work, arena_len, n_ranges, flags, n_meta = (int(x) for x in hdr)
+    pf = PlanFile()
+    pos = 72
+    pf.pairs = np.frombuffer(raw, PAIR_DTYPE, n_pairs, pos).copy()
+    pos += 96 * n_pairs
+    pf.ranges = np.frombuffer(raw, "<u8", 2 * n_ranges, pos).reshape(-1, 2).copy()
+    pos += 16 * n_ranges
+    pf.meta = np.frombuffer(raw, "<f8", n_meta, pos).copy()
+    pos += 8 * n_meta
+    pf.psi_len, pf.sigma_len, pf.max_work, pf.arena_len = psi_len, sigma_len, max_work, arena_len
+
+    def take(n):
+        nonlocal pos
+        a = np.frombuffer(raw, "<f8", n, pos).copy()
+        pos += 8 * n
+        return a
+
+    if flags & F_ARENA:
+        pf.arena = take(arena_len)
+    if flags & F_PSI:
+        pf.psi = take(psi_len)
+    if flags & F_SIGMA:
+        pf.sigma_ref = take(sigma_len)
+    if flags & F_DIAG:
+        pf.diag = take(psi_len)
+    if flags & F_PSIOUT:
+        pf.psi_out = take(psi_len)
+    return pf
+
+
+def write_plan(fn, pf):
+    flags = 0
+    for bit, arr in ((F_ARENA, pf.arena), (F_PSI, pf.psi), (F_SIGMA, pf.sigma_ref), (F_DIAG, pf.diag),
+                     (F_PSIOUT, pf.psi_out)):
+        if arr is not None:
+            flags |= bit
+    hdr = np.array([pf.n_pairs, pf.psi_len, pf.sigma_len, pf.max_work, pf.arena_len, len(pf.ranges), flags,
+                    len(pf.meta)], "<u8")
+    with open(fn, "wb") as f:
+        f.write(b"B2XPLAN1")
+        f.write(hdr.tobytes())
+        f.write(np.ascontiguousarray(pf.pairs, PAIR_DTYPE).tobytes())
+        f.write(np.ascontiguousarray(pf.ranges, "<u8").tobytes())
+        f.write(np.ascontiguousarray(pf.meta, "<f8").tobytes())
+        for arr in (pf.arena, pf.psi, pf.sigma_ref, pf.diag, pf.psi_out):
+            if arr is not None:
+                f.write(np.ascontiguousarray(arr, "<f8").tobytes())

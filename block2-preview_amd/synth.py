@@ -1,0 +1,119 @@
+"""Synthetic GEMM-pair plans (structure only; data is filled by the caller).
+
+* ``random_rotate_plan``   — the shape family of the reference's own executor test
+  (unit_test/test_batch_gemm.cpp:88-143: random dims 1..100, 1..30 outputs x 1..30 inputs, random
+  transposes), extended with row/column slices as BatchGEMMSeq::three_rotate produces them
+  (src/core/batch_gemm.hpp:952-1022).
+* ``scale_plan``           — a captured plan structure with every sector dimension multiplied by an
+  integer factor ("synthetic plans with the measured shape histograms scaled to M").
+"""
+import numpy as np
+
+from .planfile import PAIR_DTYPE, PlanFile
+
+
+def _pair(m0, n0, k0, lda0, ldb0, m1, lda1, ldc1, tb0, ta1, a0, a1, x, y, z, v):
+    p = np.zeros((), PAIR_DTYPE)
+    p["m0"], p["n0"], p["k0"], p["lda0"], p["ldb0"] = m0, n0, k0, lda0, ldb0
+    p["m1"], p["n1"], p["k1"], p["lda1"], p["ldc1"] = m1, n0, m0, lda1, ldc1
+    p["tb0"], p["ta1"], p["alpha0"], p["alpha1"] = tb0, ta1, a0, a1
+    p["x_off"], p["y_off"], p["z_off"], p["v_off"] = x, y, z, v
+    return p
+
+
+def random_rotate_plan(rng, n_sectors=4, max_dim=100, max_terms=12, slices=True):
+    """Random plan over ``n_sectors`` psi sectors / psi' sectors.  Returns a PlanFile without data."""
+    src = [(int(rng.integers(1, max_dim + 1)), int(rng.integers(1, max_dim + 1))) for _ in range(n_sectors)]
+    dst = [(int(rng.integers(1, max_dim + 1)), int(rng.integers(1, max_dim + 1))) for _ in range(n_sectors)]
+    src_off = np.concatenate([[0], np.cumsum([a * b for a, b in src])]).astype(np.int64)
+    dst_off = np.concatenate([[0], np.cumsum([a * b for a, b in dst])]).astype(np.int64)
+    pairs, arena_len = [], 0
+    for iv in range(n_sectors):
+        vm, vn = dst[iv]
+        for _ in range(int(rng.integers(1, max_terms + 1))):
+            ic = int(rng.integers(0, n_sectors))
+            cm, cn = src[ic]
+            # optional slices: rows [ar0, ar0+am) of X -> rows [vr0, vr0+cmv) of V, or the column analogue
+            mode = int(rng.integers(0, 3)) if slices else 0
+            ar0, am, ac0, an = 0, cm, 0, cn
+            vr0, vmm, vc0, vnn = 0, vm, 0, vn
+            if mode == 1:
+                am = int(rng.integers(1, cm + 1)); ar0 = int(rng.integers(0, cm - am + 1))
+                vmm = int(rng.integers(1, vm + 1)); vr0 = int(rng.integers(0, vm - vmm + 1))
+            elif mode == 2:
+                an = int(rng.integers(1, cn + 1)); ac0 = int(rng.integers(0, cn - an + 1))
+                vnn = int(rng.integers(1, vn + 1)); vc0 = int(rng.integers(0, vn - vnn + 1))
+            tb0, ta1 = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            # Y: op(Y) is an x vnn ; Z: op(Z) is vmm x am ; both dense blocks
+            y_off, arena_len = arena_len, arena_len + an * vnn
+            z_off, arena_len = arena_len, arena_len + vmm * am
+            pairs.append(_pair(
+                am, vnn, an, cn, (an if tb0 else vnn), vmm, (vmm if ta1 else am), vn, tb0, ta1,
+                float(rng.uniform(-1, 1)), float(rng.uniform(-1, 1)),
+                src_off[ic] + ar0 * cn + ac0, y_off, z_off, dst_off[iv] + vr0 * vn + vc0))
+    pf = PlanFile()
+    pf.pairs = np.array(pairs, PAIR_DTYPE)
+    pf.psi_len, pf.sigma_len, pf.arena_len = int(src_off[-1]), int(dst_off[-1]), int(arena_len)
+    pf.max_work = int((pf.pairs["m0"].astype(np.int64) * pf.pairs["n0"]).max())
+    return pf
+
+
+def _column_offsets(off, m, n, ld):
+    """Column index (inside its sector row) of the first element of each window: windows whose address
+    ranges overlap belong to one sector; the sector's rows start where a window with col 0 starts."""
+    order = np.argsort(off, kind="stable")
+    col = np.zeros(len(off), np.int64)
+    i = 0
+    while i < len(order):
+        a = order[i]
+        end = off[a] + (m[a] - 1) * ld[a] + n[a]
+        j = i + 1
+        while j < len(order) and off[order[j]] < end:
+            b = order[j]
+            end = max(end, off[b] + (m[b] - 1) * ld[b] + n[b])
+            j += 1
+        grp = order[i:j]
+        multi = [g for g in grp if m[g] > 1]
+        L = int(ld[multi[0]]) if multi else int(max(off[g] - off[grp[0]] + n[g] for g in grp))
+        base = int(off[grp[0]])
+        c0 = 0
+        for g in grp:
+            if (int(off[g]) - base + c0) % L + int(n[g]) > L:
+                c0 = (L - (int(off[g]) - base) % L) % L
+        for g in grp:
+            col[g] = (int(off[g]) - base + c0) % L
+        i = j
+    return col
+
+
+def scale_plan(pf, f):
+    """Every sector dimension x f (offsets follow: f*f on whole rows, f on the in-row column offset)."""
+    f = int(f)
+    p = pf.pairs.copy()
+    i64 = lambda a: a.astype(np.int64)
+    xc = _column_offsets(i64(p["x_off"]), i64(p["m0"]), i64(p["k0"]), i64(p["lda0"]))
+    vc = _column_offsets(i64(p["v_off"]), i64(p["m1"]), i64(p["n1"]), i64(p["ldc1"]))
+    q = p.copy()
+    for nm in ("m0", "n0", "k0", "lda0", "ldb0", "m1", "n1", "k1", "lda1", "ldc1"):
+        q[nm] = p[nm] * f
+    q["x_off"] = (f * f * (i64(p["x_off"]) - xc) + f * xc).astype(np.uint64)
+    q["v_off"] = (f * f * (i64(p["v_off"]) - vc) + f * vc).astype(np.uint64)
+    q["y_off"] = (f * f * i64(p["y_off"])).astype(np.uint64)
+    q["z_off"] = (f * f * i64(p["z_off"])).astype(np.uint64)
+    out = PlanFile()
+    out.pairs = q
+    out.psi_len, out.sigma_len, out.arena_len = pf.psi_len * f * f, pf.sigma_len * f * f, pf.arena_len * f * f
+    out.max_work = pf.max_work * f * f
+    out.meta = pf.meta.copy()
+    return out
+
+
+def shard_pairs(pairs, rank, world):
+    """sum-MPO style sharding of one plan: every operator TERM (here: distinct stage-1 left operator
+    block z_off, i.e. one left-block operator of the MPO bond) is owned by exactly one rank, as
+    ParallelRuleSimple::index_prefactor assigns integrals (src/dmrg/parallel_simple.hpp:56-99).
+    The partial sigma of all ranks sums to the full H psi."""
+    if world == 1:
+        return pairs
+    _, inv = np.unique(pairs["z_off"], return_inverse=True)
+    return pairs[(inv % world) == rank]

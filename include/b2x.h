@@ -1,0 +1,147 @@
+/*
+ * b2x.h — C ABI of the MI355X-native H·psi (effective-Hamiltonian contraction) path.
+ *
+ * This is the drop-in boundary for block2's GEMM-pair plan replay.  Every entry point
+ * names the reference interface it replaces (paths relative to the block2 source tree):
+ *
+ *   plan build    <- BatchGEMMSeq<double>::rotate / three_rotate   src/core/batch_gemm.hpp:893-902, 952-1022
+ *                    (what EffectiveHamiltonian::precompute() records, src/dmrg/effective_hamiltonian.hpp:224-244)
+ *   plan execute  <- BatchGEMMSeq<double>::operator()(c, v, scale) src/core/batch_gemm.hpp:1563-1684 (Tasked branch)
+ *                    reached from TensorFunctions::operator()      src/core/tensor_functions.hpp:59-62
+ *   plan destroy  <- EffectiveHamiltonian::post_precompute()       src/dmrg/effective_hamiltonian.hpp:245-251
+ *   all-reduce    <- ParallelCommunicator::allreduce_sum(double*, size_t)  src/core/parallel_rule.hpp:55
+ *                    (MPI body: src/core/parallel_mpi.hpp:300-309), called by
+ *                    ParallelTensorFunctions::operator()           src/core/parallel_tensor_functions.hpp:51-55
+ *   vector ops    <- the BLAS-1 calls of IterativeMatrixFunctions::davidson
+ *                    src/core/iterative_matrix_functions.hpp:864-1173 (ddot/daxpy/dscal/dcopy on |psi| vectors)
+ *
+ * Conventions: plain pointers and sizes only; every function returns 0 on success and a
+ * non-zero code on failure (b2x_last_error() gives the text).  The C++ host wrapper turns a
+ * non-zero return into std::runtime_error, matching the reference's error convention.
+ * All matrices are ROW-MAJOR with explicit leading dimension, as GMatrix (src/core/matrix.hpp:92-107).
+ */
+#ifndef B2X_H
+#define B2X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define B2X_OK 0
+#define B2X_ERR_INVALID 1  /* bad argument / unsupported descriptor */
+#define B2X_ERR_DEVICE 2   /* HIP runtime failure */
+#define B2X_ERR_NOMEM 3
+#define B2X_ERR_STATE 4
+
+/*
+ * One GEMM pair of the plan (real double: exactly one stage-0 and one stage-1 descriptor per
+ * H·psi term; batch[0] / batch[1] slots i of BatchGEMMSeq, src/core/batch_gemm.hpp:237-247).
+ *
+ *   stage 0:  W (m0 x n0)  = alpha0 * opA0(X)(m0 x k0) * opB0(Y)(k0 x n0)          beta = 0
+ *   stage 1:  V (m1 x n1) += alpha1 * scale * opA1(Z)(m1 x k1) * opB1(W)(k1 x n1)  beta = 1
+ *
+ * X is a slice of psi (x_off = batch[0]->a[i], an element offset "from null"), Y and Z are
+ * operator blocks (absolute host pointers in the reference; arena element offsets here),
+ * V is a slice of psi' (v_off = batch[1]->c[i]).  W is pair-local (never leaves the chip).
+ * On this path ta0 = tb1 = 0, k1 = m0, n1 = n0, ldc0 = ldb1 = n0.
+ */
+typedef struct b2x_pair {
+    int32_t m0, n0, k0;
+    int32_t lda0, ldb0;
+    int32_t m1, n1, k1;
+    int32_t lda1, ldc1;
+    uint8_t ta0, tb0, ta1, tb1; /* 0 = no transpose, 1 = transpose */
+    uint32_t reserved;
+    double alpha0, alpha1;
+    uint64_t x_off; /* psi   element offset */
+    uint64_t y_off; /* arena element offset (stage-0 B operand) */
+    uint64_t z_off; /* arena element offset (stage-1 A operand) */
+    uint64_t v_off; /* psi'  element offset */
+} b2x_pair;
+
+typedef struct b2x_arena b2x_arena;
+typedef struct b2x_plan b2x_plan;
+typedef struct b2x_comm b2x_comm;
+
+typedef struct b2x_plan_stats {
+    uint64_t n_pairs;
+    uint64_t macs;            /* sum m0*n0*k0 + m1*n1*k1 == reference nflop (batch_gemm.hpp:307) */
+    uint64_t op_elems_unique; /* distinct operator elements referenced by the plan */
+    uint64_t psi_len, sigma_len;
+    uint64_t n_targets;       /* disjoint psi' output regions after overlap merging */
+    uint64_t n_tiles;         /* output tiles */
+    uint64_t n_items;         /* work items (tile x pair-chunk) launched per execute */
+    uint64_t n_parts;         /* (pair x tile) parts */
+    uint64_t device_bytes;    /* plan metadata + partial-sum slabs resident in HBM */
+    uint64_t macs_executed;   /* MACs the tiled kernels really issue (>= macs: stage 0 is recomputed per row tile) */
+    uint64_t dominant_class;  /* kernel class that carries most MACs */
+    uint64_t macs_dominant;   /* MACs executed by the dominant class */
+} b2x_plan_stats;
+
+/* tuning knobs; pass NULL for defaults */
+typedef struct b2x_plan_options {
+    int32_t tile_m, tile_n;       /* 0 = auto */
+    int32_t kernel;               /* 0 = auto, 1 = scalar reference kernel, 2 = MFMA kernel */
+    int64_t item_macs;            /* target MACs per work item (0 = auto) */
+    int32_t reserved[8];
+} b2x_plan_options;
+
+const char *b2x_last_error(void);
+const char *b2x_version(void);
+
+/* device ------------------------------------------------------------------------------- */
+int b2x_device_count(int *n);
+int b2x_device_init(int ordinal);                 /* hipSetDevice; fails if no gfx950 device */
+int b2x_device_sync(void);
+int b2x_device_alloc(void **dptr, size_t bytes);  /* hipMalloc  */
+int b2x_device_free(void *dptr);
+int b2x_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int b2x_memcpy_d2h(void *dst, const void *src, size_t bytes);
+
+/* operator arena ---------------------------------------------------------------------------
+ * Replaces: the heap-resident operator blocks OperatorTensor::ops[*]->data that the reference
+ * plan points into (src/core/operator_tensor.hpp:47; immutable for one EffectiveHamiltonian). */
+int b2x_arena_create(b2x_arena **out, size_t n_ranges, const double *const *host_bases,
+                     const size_t *lens);               /* concatenates + uploads */
+int b2x_arena_adopt_device(b2x_arena **out, double *dev_base, size_t len); /* no copy, not owned */
+int b2x_arena_resolve(const b2x_arena *a, const double *host_ptr, uint64_t *off);
+int b2x_arena_len(const b2x_arena *a, uint64_t *len);
+int b2x_arena_device_ptr(const b2x_arena *a, double **dev_base);
+int b2x_arena_destroy(b2x_arena *a);
+
+/* plan -------------------------------------------------------------------------------------- */
+int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, const b2x_pair *pairs,
+                    size_t psi_len, size_t sigma_len, const b2x_plan_options *opt);
+/* sigma += scale * H * psi.  on_device != 0: psi/sigma are device pointers (no copies);
+ * stream: hipStream_t (NULL = default stream).  Asynchronous when on_device != 0. */
+int b2x_plan_execute(b2x_plan *p, const double *psi, double *sigma, double scale, int on_device,
+                     void *stream);
+int b2x_plan_get_stats(const b2x_plan *p, b2x_plan_stats *st);
+/* time n launches of the dominant kernel with HIP events on `stream`; returns average ms */
+int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, int n, void *stream,
+                         double *avg_ms_main, double *avg_ms_total);
+int b2x_plan_destroy(b2x_plan *p);
+
+/* device-resident vector algebra for Davidson (all pointers are device pointers) ------------ */
+int b2x_vec_dot(const double *x, const double *y, size_t n, double *host_result, void *stream);
+int b2x_vec_axpy(double a, const double *x, double *y, size_t n, void *stream);   /* y += a x */
+int b2x_vec_scal(double a, double *x, size_t n, void *stream);
+int b2x_vec_copy(const double *x, double *y, size_t n, void *stream);
+int b2x_vec_zero(double *x, size_t n, void *stream);
+/* Olsen/diagonal preconditioner step of davidson (iterative_matrix_functions.hpp:1084-1087):
+ * q[i] /= (diag[i] - shift) when |diag[i]-shift| > 1e-12 */
+int b2x_vec_precondition(double *q, const double *diag, double shift, size_t n, void *stream);
+/* gram[j] = <vs[j], x> for j < nv; vs = nv device pointers (host array of device pointers) */
+int b2x_vec_multi_dot(const double *const *vs, int nv, const double *x, size_t n, double *host_result,
+                      void *stream);
+/* y = sum_j coef[j] * vs[j] */
+int b2x_vec_lincomb(const double *const *vs, int nv, const double *coef, double *y, size_t n,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

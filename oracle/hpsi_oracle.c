@@ -1,0 +1,164 @@
+/*
+ * hpsi_oracle.c — CPU restatement of block2's GEMM-pair plan replay.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (block2-preview_amd/, include/)
+ * may link, import or call this file; it exists so tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py can check the HIP path against an independent implementation.
+ *
+ * Parity pin: validated in the authoring container against (1) golden plans captured from the
+ * real reference (tests/golden/*.plan: sigma_ref produced by TensorFunctions::operator() of the
+ * reference itself, see oracle/ref_dump.cpp) and (2) oracle/_ref/ref_replay, which replays the
+ * same plan through the reference's BatchGEMMSeq::operator().  GEMM is not bit-specified at the
+ * BLAS boundary (the reference's own tests use 1e-10, unit_test/test_batch_gemm.cpp:88-143), so
+ * agreement is to rounding, not bitwise.
+ *
+ * What each function follows (paths relative to the reference tree):
+ *   b2x_oracle_gemm    GMatrixFunctions<double>::multiply   src/core/matrix_functions.hpp:943-968
+ *                      (row-major C = alpha op(A) op(B) + beta C, issued to column-major dgemm as
+ *                       xgemm(trb, tra, n, m, k, alpha, B, ldb, A, lda, beta, C, ldc),
+ *                       src/core/batch_gemm.hpp:75-82, 197-203, 229-233)
+ *   b2x_oracle_rotate  GMatrixFunctions<double>::rotate     src/core/matrix_functions.hpp:973-984
+ *   b2x_oracle_replay  BatchGEMMSeq<double>::operator()     src/core/batch_gemm.hpp:1606-1682 (Tasked):
+ *                      static split of the pair list over threads, per pair
+ *                        perform_single(stage 0) into thread-local W   (:1630-1632, :359-364, :207-234)
+ *                        perform_single(stage 1, scale) into thread-private psi'   (:1633-1635)
+ *                      then parallel_reduce tree sum of the private copies (:1507-1523, :1673-1674).
+ */
+#include "../include/b2x.h"
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* row-major C(m x n) = alpha * opA(A)(m x k) * opB(B)(k x n) + beta * C ; beta == 0 overwrites
+ * (BLAS semantics: C is not read when beta == 0). */
+void b2x_oracle_gemm(int ta, int tb, int m, int n, int k, double alpha, const double *a, int lda,
+                     const double *b, int ldb, double beta, double *c, int ldc) {
+    for (int i = 0; i < m; i++) {
+        double *ci = c + (size_t)i * ldc;
+        if (beta == 0.0)
+            for (int j = 0; j < n; j++)
+                ci[j] = 0.0;
+        else if (beta != 1.0)
+            for (int j = 0; j < n; j++)
+                ci[j] *= beta;
+        if (!tb) {
+            for (int l = 0; l < k; l++) {
+                double ail = alpha * (ta ? a[(size_t)l * lda + i] : a[(size_t)i * lda + l]);
+                const double *bl = b + (size_t)l * ldb;
+                for (int j = 0; j < n; j++)
+                    ci[j] += ail * bl[j];
+            }
+        } else {
+            for (int j = 0; j < n; j++) {
+                const double *bj = b + (size_t)j * ldb;
+                double s = 0.0;
+                if (!ta) {
+                    const double *ai = a + (size_t)i * lda;
+                    for (int l = 0; l < k; l++)
+                        s += ai[l] * bj[l];
+                } else
+                    for (int l = 0; l < k; l++)
+                        s += a[(size_t)l * lda + i] * bj[l];
+                ci[j] += alpha * s;
+            }
+        }
+    }
+}
+
+/* c(l x r) += scale * op(bra) * a * op(ket); conj_bra / conj_ket are transpose flags.
+ * a: (am x an) dense; ket: stored (kr x kc); bra stored (br x bc); work >= am * r doubles. */
+void b2x_oracle_rotate(const double *a, int am, int an, double *c, int cm, int cn, const double *bra,
+                       int br, int bc, int conj_bra, const double *ket, int kr, int kc, int conj_ket,
+                       double scale, double *work) {
+    int wn = conj_ket ? kr : kc;
+    b2x_oracle_gemm(0, conj_ket, am, wn, an, 1.0, a, an, ket, kc, 0.0, work, wn);
+    b2x_oracle_gemm(conj_bra, 0, cm, cn, am, scale, bra, bc, work, wn, 1.0, c, cn);
+}
+
+static void run_pair(const b2x_pair *p, const double *arena, const double *psi, double *sigma,
+                     double scale, double *work) {
+    b2x_oracle_gemm(p->ta0, p->tb0, p->m0, p->n0, p->k0, p->alpha0, psi + p->x_off, p->lda0,
+                    arena + p->y_off, p->ldb0, 0.0, work, p->n0);
+    b2x_oracle_gemm(p->ta1, p->tb1, p->m1, p->n1, p->k1, p->alpha1 * scale, arena + p->z_off,
+                    p->lda1, work, p->n0, 1.0, sigma + p->v_off, p->ldc1);
+}
+
+static void tree_reduce(double **vs, size_t len, int i, int j) {
+    if (j - i <= 1)
+        return;
+    int m = (i + j) >> 1;
+    tree_reduce(vs, len, i, m);
+    tree_reduce(vs, len, m, j);
+    for (size_t x = 0; x < len; x++)
+        vs[i][x] += vs[m][x];
+}
+
+/* sigma += scale * H * psi.  Returns the MAC count (reference nflop). */
+uint64_t b2x_oracle_replay(uint64_t n_pairs, const b2x_pair *pairs, const double *arena,
+                           const double *psi, double *sigma, uint64_t sigma_len, double scale,
+                           int nthreads) {
+    uint64_t macs = 0, max_work = 1;
+    for (uint64_t i = 0; i < n_pairs; i++) {
+        const b2x_pair *p = &pairs[i];
+        macs += (uint64_t)p->m0 * p->n0 * p->k0 + (uint64_t)p->m1 * p->n1 * p->k1;
+        uint64_t w = (uint64_t)p->m0 * p->n0;
+        if (w > max_work)
+            max_work = w;
+    }
+    if (nthreads < 1)
+        nthreads = 1;
+    double **vts = (double **)calloc((size_t)nthreads, sizeof(double *));
+    vts[0] = sigma;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        int tid = 0, nt = 1;
+#ifdef _OPENMP
+        tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#endif
+        double *work = (double *)malloc(max_work * sizeof(double));
+        if (tid != 0)
+            vts[tid] = (double *)calloc(sigma_len ? sigma_len : 1, sizeof(double));
+        /* schedule(static): contiguous chunks in pair order */
+        uint64_t chunk = (n_pairs + (uint64_t)nt - 1) / (uint64_t)nt;
+        uint64_t lo = chunk * (uint64_t)tid, hi = lo + chunk < n_pairs ? lo + chunk : n_pairs;
+        for (uint64_t i = lo; i < hi; i++)
+            run_pair(&pairs[i], arena, psi, vts[tid], scale, work);
+        free(work);
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp single
+#endif
+        {
+            /* threads beyond the team size (if the runtime gave fewer) have NULL copies */
+            int live = 0;
+            while (live < nthreads && vts[live] != NULL)
+                live++;
+            tree_reduce(vts, sigma_len, 0, live);
+        }
+    }
+    for (int t = 1; t < nthreads; t++)
+        free(vts[t]);
+    free(vts);
+    return macs;
+}
+
+/* expand the plan into a dense matrix H (sigma_len x psi_len, row-major), for tiny cases:
+ * column j = replay applied to unit vector e_j.  Used by tests to cross-check Davidson. */
+void b2x_oracle_dense(uint64_t n_pairs, const b2x_pair *pairs, const double *arena, uint64_t psi_len,
+                      uint64_t sigma_len, double *h) {
+    double *e = (double *)calloc(psi_len, sizeof(double));
+    double *s = (double *)malloc(sigma_len * sizeof(double));
+    for (uint64_t j = 0; j < psi_len; j++) {
+        e[j] = 1.0;
+        memset(s, 0, sigma_len * sizeof(double));
+        b2x_oracle_replay(n_pairs, pairs, arena, e, s, sigma_len, 1.0, 1);
+        for (uint64_t i = 0; i < sigma_len; i++)
+            h[i * psi_len + j] = s[i];
+        e[j] = 0.0;
+    }
+    free(e), free(s);
+}

@@ -1,0 +1,47 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_plan_files():
+    return sorted(glob.glob(os.path.join(GOLDEN, "*.plan")))
+
+
+@pytest.fixture(scope="session")
+def built():
+    """libb2x.so + liboracle.so present (built in-tree; hipcc cross-compiles without a GPU)."""
+    import __graft_entry__ as ge
+
+    ge.build()
+    return True
+
+
+@pytest.fixture(scope="session")
+def gpu(built):
+    from block2_preview_amd import capi
+
+    if capi.device_count() == 0:
+        pytest.fail("GPU test selected but no HIP device is visible (there is no CPU fallback)")
+    capi.device_init(0)
+    return capi
+
+
+def fill_plan(pf, seed):
+    """uniform [0,1) operator / psi data, like Random::fill of the reference (src/core/utils.hpp:247-252)"""
+    rng = np.random.default_rng(seed)
+    pf.arena = rng.random(pf.arena_len)
+    pf.psi = rng.random(pf.psi_len)
+    return pf

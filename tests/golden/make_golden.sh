@@ -1,0 +1,14 @@
+#!/bin/bash
+# Regenerates the golden plans in this directory FROM THE REAL REFERENCE (authoring container only:
+# needs /root/reference and oracle/_ref/ref_dump built by `make -C oracle ref`).
+# Each *.plan holds: the GEMM-pair plan recorded by EffectiveHamiltonian::precompute(), the operator
+# blocks it points to, psi, diag and sigma_ref = H psi computed by the reference's own
+# TensorFunctions::operator() (Tasked BatchGEMMSeq replay).  *.log holds per-site / final energies.
+set -e
+cd "$(dirname "$0")"
+export MKL_THREADING_LAYER=GNU
+R=../../oracle/_ref/ref_dump
+D=/root/reference/data
+$R $D/N2.STO3G.FCIDUMP su2 200 10 ./n2su2 dump=0:4,2:5 iprint=0          # E = -107.654122447525 (test_dmrg_n2_sto3g.cpp:187)
+$R $D/N2.STO3G.FCIDUMP sz 60 6 ./n2sz dump=1:6,2:4 iprint=0
+$R $D/H10.STO6G.R1.8.FCIDUMP sz 50 6 ./h10szm50 dump=0:6,1:5,2:4 iprint=0

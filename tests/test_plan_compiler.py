@@ -1,0 +1,70 @@
+"""The plan COMPILER (pairs -> tiles/parts/items, block2-preview_amd/csrc/b2x_plan.cpp) checked on the CPU:
+the compiled work list, evaluated with plain host loops through the test hook
+b2x_debug_compile_and_emulate, must reproduce the oracle.  (The HIP kernels that consume the same work
+list are checked against the oracle in test_hpsi_gpu.py.)"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import fill_plan, golden_plan_files
+from block2_preview_amd import capi, synth
+from block2_preview_amd.planfile import PAIR_DTYPE, read_plan
+from oracle import oracle
+
+FILES = golden_plan_files()
+
+
+def _check(pf, **kw):
+    ref = np.zeros(pf.sigma_len)
+    oracle.replay(pf.pairs, pf.arena, pf.psi, ref, 0.75)
+    sig = np.zeros(pf.sigma_len)
+    st, fb = capi.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, pf.arena, pf.psi, sig, 0.75, **kw)
+    assert not fb
+    assert st["macs"] == pf.macs
+    assert np.abs(sig - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+    return st
+
+
+@pytest.mark.parametrize("fn", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_compiled_golden(built, fn):
+    _check(read_plan(fn))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_compiled_random_with_slices(built, seed):
+    rng = np.random.default_rng(100 + seed)
+    pf = fill_plan(synth.random_rotate_plan(rng, n_sectors=4, max_dim=90, max_terms=6), seed)
+    st = _check(pf)
+    assert st["n_targets"] <= 4  # overlapping row/col slices merge into their sector
+
+
+@pytest.mark.parametrize("tile_n,item_macs", [(16, 1), (32, 50000), (64, 0), (128, 1 << 40)])
+def test_compiled_forced_classes_and_item_sizes(built, tile_n, item_macs):
+    """every kernel class / split granularity yields the same sum (k1 chunking, multi-tile, multi-item)"""
+    rng = np.random.default_rng(5)
+    pf = fill_plan(synth.random_rotate_plan(rng, n_sectors=3, max_dim=150, max_terms=4), 5)
+    _check(pf, tile_n=tile_n, item_macs=item_macs)
+
+
+def test_scaled_structure_consistent(built):
+    """scale_plan keeps the plan well-formed (what bench.py feeds the GPU at M=4000 scale)"""
+    pf = read_plan([f for f in FILES if "h10szm50.sw0.site6" in f][0])  # has column slices
+    big = fill_plan(synth.scale_plan(pf, 2), 3)
+    assert big.macs == 8 * pf.macs
+    _check(big)
+
+
+def test_empty_and_invalid(built):
+    st, fb = capi.debug_compile_and_emulate(np.zeros(0, PAIR_DTYPE), 10, 10, np.zeros(4), np.zeros(10), np.zeros(10))
+    assert st["n_pairs"] == 0 and not fb
+    bad = np.zeros(1, PAIR_DTYPE)
+    bad["m0"] = bad["n0"] = bad["k0"] = bad["m1"] = bad["n1"] = bad["k1"] = 4
+    bad["lda0"] = bad["ldb0"] = bad["lda1"] = bad["ldc1"] = 4
+    bad["x_off"] = 100  # runs past psi
+    with pytest.raises(capi.B2XError):
+        capi.debug_compile_and_emulate(bad, 16, 16, np.zeros(32), np.zeros(16), np.zeros(16))
+    bad["x_off"] = 0
+    bad["ta0"] = 1  # unsupported on this path
+    with pytest.raises(capi.B2XError):
+        capi.debug_compile_and_emulate(bad, 16, 16, np.zeros(32), np.zeros(16), np.zeros(16))
