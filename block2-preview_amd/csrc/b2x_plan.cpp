@@ -165,6 +165,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     };
     int64_t total_cost = 0;
     uint64_t cls_macs[kNumClasses] = {0, 0, 0, 0};
+    double cls_alg[kNumClasses] = {0, 0, 0, 0};
     std::vector<HostTile> htiles;
     for (const Component &c : comps) {
         // class by shape: columns decide the number of waves, rows the fragment count
@@ -237,6 +238,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         ht.cost.push_back(cst);
                         total_cost += (int64_t)cst;
                         cls_macs[cls] += (uint64_t)p.k1 * d.nc * p.k0 + (uint64_t)d.mr * d.nc * p.k1;
+                        // algorithmic share: stage 0 of a pair counted once over its row tiles
+                        cls_alg[cls] += (double)p.k1 * d.nc * p.k0 * ((double)d.mr / p.m1) + (double)d.mr * d.nc * p.k1;
                     }
                 }
         }
@@ -292,6 +295,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     }
     st.macs_executed = cls_macs[0] + cls_macs[1] + cls_macs[2] + cls_macs[3];
     st.macs_dominant = cls_macs[st.dominant_class];
+    st.macs_alg_dominant = (uint64_t)(cls_alg[st.dominant_class] + 0.5);
     st.device_bytes = slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
     return B2X_OK;
 }

@@ -96,3 +96,24 @@ def write_plan(fn, pf):
         for arr in (pf.arena, pf.psi, pf.sigma_ref, pf.diag, pf.psi_out):
             if arr is not None:
                 f.write(np.ascontiguousarray(arr, "<f8").tobytes())
+
+
+def write_struct_npz(fn, pf):
+    """Structure-only plan (no operator / psi data) as compressed columns — a 100k-pair plan is < 1 MB."""
+    cols = {n: pf.pairs[n] for n in PAIR_DTYPE.names if n != "reserved"}
+    np.savez_compressed(fn, psi_len=pf.psi_len, sigma_len=pf.sigma_len, arena_len=pf.arena_len,
+                        max_work=pf.max_work, meta=pf.meta, **cols)
+
+
+def read_struct_npz(fn):
+    z = np.load(fn, allow_pickle=False)
+    pf = PlanFile()
+    n = len(z["m0"])
+    pf.pairs = np.zeros(n, PAIR_DTYPE)
+    for name in PAIR_DTYPE.names:
+        if name != "reserved":
+            pf.pairs[name] = z[name]
+    pf.psi_len, pf.sigma_len = int(z["psi_len"]), int(z["sigma_len"])
+    pf.arena_len, pf.max_work = int(z["arena_len"]), int(z["max_work"])
+    pf.meta = z["meta"].copy()
+    return pf

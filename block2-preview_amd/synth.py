@@ -117,3 +117,33 @@ def shard_pairs(pairs, rank, world):
         return pairs
     _, inv = np.unique(pairs["z_off"], return_inverse=True)
     return pairs[(inv % world) == rank]
+
+
+def compact_arena(pairs):
+    """Renumber y_off / z_off so that only the operator blocks these pairs reference remain, packed
+    back to back (what one sum-MPO rank actually holds).  Returns (pairs, arena_len)."""
+    p = pairs.copy()
+    ey = np.where(p["tb0"] == 1, (p["n0"].astype(np.int64) - 1) * p["ldb0"] + p["k0"],
+                  (p["k0"].astype(np.int64) - 1) * p["ldb0"] + p["n0"])
+    ez = np.where(p["ta1"] == 1, (p["k1"].astype(np.int64) - 1) * p["lda1"] + p["m1"],
+                  (p["m1"].astype(np.int64) - 1) * p["lda1"] + p["k1"])
+    start = np.concatenate([p["y_off"].astype(np.int64), p["z_off"].astype(np.int64)])
+    end = start + np.concatenate([ey, ez])
+    order = np.argsort(start, kind="stable")
+    s, e = start[order], end[order]
+    # merge overlapping ranges
+    run_end = np.maximum.accumulate(e)
+    new_run = np.ones(len(s), bool)
+    new_run[1:] = s[1:] >= run_end[:-1]
+    run_id = np.cumsum(new_run) - 1
+    run_start = s[new_run]
+    run_stop = np.zeros(run_id[-1] + 1 if len(s) else 0, np.int64)
+    np.maximum.at(run_stop, run_id, e)
+    run_len = run_stop - run_start
+    run_new = np.concatenate([[0], np.cumsum(run_len)])
+    new_start = np.empty(len(s), np.int64)
+    new_start[order] = run_new[run_id] + (s - run_start[run_id])
+    n = len(p)
+    p["y_off"] = new_start[:n].astype(np.uint64)
+    p["z_off"] = new_start[n:].astype(np.uint64)
+    return p, int(run_new[-1])

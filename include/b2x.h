@@ -79,6 +79,7 @@ typedef struct b2x_plan_stats {
     uint64_t macs_executed;   /* MACs the tiled kernels really issue (>= macs: stage 0 is recomputed per row tile) */
     uint64_t dominant_class;  /* kernel class that carries most MACs */
     uint64_t macs_dominant;   /* MACs executed by the dominant class */
+    uint64_t macs_alg_dominant; /* algorithmic (reference-count) MACs of the pairs in the dominant class */
 } b2x_plan_stats;
 
 /* tuning knobs; pass NULL for defaults */

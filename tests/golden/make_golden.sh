@@ -12,3 +12,7 @@ D=/root/reference/data
 $R $D/N2.STO3G.FCIDUMP su2 200 10 ./n2su2 dump=0:4,2:5 iprint=0          # E = -107.654122447525 (test_dmrg_n2_sto3g.cpp:187)
 $R $D/N2.STO3G.FCIDUMP sz 60 6 ./n2sz dump=1:6,2:4 iprint=0
 $R $D/H10.STO6G.R1.8.FCIDUMP sz 50 6 ./h10szm50 dump=0:6,1:5,2:4 iprint=0
+# Cr2/SVP structure-only plans (pair descriptors, no operator data), converted to .struct.npz by
+#   python -c "from block2_preview_amd.planfile import *; write_struct_npz(out, read_plan(in))"
+# (the run ends with a harmless crash in the reference's teardown after all files are written)
+$R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2m250 struct=1:5,1:10,1:20,1:30,0:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
