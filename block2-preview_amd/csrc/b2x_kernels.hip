@@ -154,6 +154,155 @@ __global__ __launch_bounds__(NW * 64) void hpsi_main(const DPart *__restrict__ p
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gg_kernel<TMF, CF>: grouped GEMM of the two-stage path (large sectors).  One workgroup of 4 waves
+// (one per SIMD, up to 512 VGPRs each) owns a (TMF*16) x (4*CF*16) output tile and walks a list of
+// K-segments   C[window] += A(mr x K) * B(K x nc).
+//   stage 0 items: one segment, A = X (psi), B = op(Y) (arena), tile stored (x alpha) into the W scratch
+//   stage 1 items: many segments, A = op(Z) (arena), B = W (scratch), tile stored into a partial slab
+// Wave w owns CF column fragments x all TMF row fragments (acc = TMF*CF*8 VGPRs).  A chunks (16 k)
+// are staged global -> registers -> LDS one chunk ahead (double-buffered LDS, one barrier per chunk);
+// B fragments are private to a wave and are prefetched one chunk ahead straight into registers.
+template <int TMF, int CF>
+__global__ __launch_bounds__(256, 1) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
+                                                     const double *__restrict__ arena,
+                                                     const double *__restrict__ psi, double *__restrict__ scratch,
+                                                     double *__restrict__ slabs) {
+    constexpr int TM = TMF * 16, LDX = 18;
+    constexpr int LDZT = (TM % 32 == 0) ? TM + 16 : TM;
+    constexpr int ABUF = (TM * LDX > 16 * LDZT) ? TM * LDX : 16 * LDZT;
+    constexpr int NA = TM * 16 / 256; // A elements staged per thread per chunk
+    __shared__ double lds[2 * ABUF];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const GItem item = items[blockIdx.x];
+
+    v4d acc[TMF][CF];
+#pragma unroll
+    for (int f = 0; f < TMF; f++)
+#pragma unroll
+        for (int q = 0; q < CF; q++)
+            acc[f][q] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    double areg[NA];
+    double bnxt[CF][4], bcur[CF][4];
+
+    // issue the global loads of one 16-k chunk of segment S at k offset kb
+    auto fetch = [&](const GSeg &S, int kb) {
+        const double *A = (S.a_src == 0 ? arena : (S.a_src == 1 ? psi : scratch)) + S.a_off;
+        const double *B = (S.b_src == 0 ? arena : (S.b_src == 1 ? psi : scratch)) + S.b_off;
+        const bool kmaj = (S.a_sk != 1); // A stored with the row index contiguous
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            int e = tid + 256 * i;
+            int row = kmaj ? (e % TM) : (e >> 4);
+            int kk = kmaj ? (e / TM) : (e & 15);
+            int rr = row - S.tr0;
+            double v = 0.0;
+            if (rr >= 0 && rr < S.mr && kb + kk < S.K)
+                v = A[(int64_t)rr * S.a_sr + (int64_t)(kb + kk) * S.a_sk];
+            areg[i] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < CF; q++) {
+            int cc = wave * (CF * 16) + q * 16 + c - S.tc0;
+            bool ok = cc >= 0 && cc < S.nc;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                int k = kb + 4 * s + g;
+                bnxt[q][s] = (ok && k < S.K) ? B[(int64_t)k * S.b_sk + (int64_t)cc * S.b_sc] : 0.0;
+            }
+        }
+    };
+    // registers -> LDS buffer
+    auto commit = [&](const GSeg &S, double *As) {
+        const bool kmaj = (S.a_sk != 1);
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            int e = tid + 256 * i;
+            if (kmaj)
+                As[(e / TM) * LDZT + (e % TM)] = areg[i];
+            else
+                As[(e >> 4) * LDX + (e & 15)] = areg[i];
+        }
+#pragma unroll
+        for (int q = 0; q < CF; q++)
+#pragma unroll
+            for (int s = 0; s < 4; s++)
+                bcur[q][s] = bnxt[q][s];
+    };
+
+    uint32_t si = item.seg_begin;
+    if (si < item.seg_end) {
+        GSeg S = segs[si];
+        int kb = 0, buf = 0;
+        fetch(S, 0);
+        commit(S, lds);
+        __syncthreads();
+        while (true) {
+            // next chunk of the flattened (segment, k) walk
+            uint32_t nsi = si;
+            int nkb = kb + 16;
+            if (nkb >= S.K)
+                nsi = si + 1, nkb = 0;
+            const bool more = nsi < item.seg_end;
+            GSeg Sn = S;
+            if (more && nsi != si)
+                Sn = segs[nsi];
+            if (more)
+                fetch(Sn, nkb);
+            // ---- compute the chunk resident in LDS ----
+            {
+                const double *As = lds + buf * ABUF;
+                const bool kmaj = (S.a_sk != 1);
+                const int lsr = kmaj ? 1 : LDX, lsk = kmaj ? LDZT : 1;
+                const int f_lo = S.tr0 >> 4, f_hi = (S.tr0 + S.mr + 15) >> 4;
+                bool qon[CF];
+#pragma unroll
+                for (int q = 0; q < CF; q++) {
+                    int c0 = wave * (CF * 16) + q * 16;
+                    qon[q] = (c0 + 16 > S.tc0) && (c0 < S.tc0 + S.nc);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+#pragma unroll
+                    for (int f = 0; f < TMF; f++)
+                        if (f >= f_lo && f < f_hi) {
+                            double a = As[(f * 16 + c) * lsr + (4 * s + g) * lsk];
+#pragma unroll
+                            for (int q = 0; q < CF; q++)
+                                if (qon[q])
+                                    acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][s], acc[f][q], 0, 0, 0);
+                        }
+                }
+            }
+            if (!more)
+                break;
+            buf ^= 1;
+            commit(Sn, lds + buf * ABUF);
+            __syncthreads();
+            S = Sn, si = nsi, kb = nkb;
+        }
+    }
+    // ---- store the tile ----
+    double *out = (item.out_kind ? scratch : slabs) + item.out_off;
+#pragma unroll
+    for (int q = 0; q < CF; q++) {
+        const int col = wave * (CF * 16) + q * 16 + c;
+        if (col < item.cols) {
+#pragma unroll
+            for (int f = 0; f < TMF; f++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int row = f * 16 + 4 * r + g;
+                    if (row < item.rows)
+                        out[(int64_t)row * item.out_ld + col] = item.alpha * acc[f][q][r];
+                }
+        }
+    }
+}
+
 // psi'[tile] += scale * sum_i slab_i[tile]   (fixed order i = 0..n_items-1)
 __global__ __launch_bounds__(256) void hpsi_reduce(const DTile *__restrict__ tiles, const double *__restrict__ slabs,
                                                     double *__restrict__ sigma, double scale) {
@@ -302,6 +451,15 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
         return launch_main_t<8, 16, 8>(parts, items, n_items, arena, psi, slabs, st);
     }
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_gg(const GSeg *segs, const GItem *items, uint32_t n_items, const double *arena, const double *psi,
+                     double *scratch, double *slabs, hipStream_t st) {
+    if (n_items == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL((gg_kernel<kGGTileM / 16, kGGTileN / 64>), dim3(n_items), dim3(256), 0, st, segs, items, arena,
+                       psi, scratch, slabs);
+    return hipGetLastError();
 }
 
 hipError_t launch_reduce(const DTile *tiles, uint32_t n_tiles, const double *slabs, double *sigma, double scale,

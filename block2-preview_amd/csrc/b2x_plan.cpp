@@ -167,7 +167,13 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     uint64_t cls_macs[kNumClasses] = {0, 0, 0, 0};
     double cls_alg[kNumClasses] = {0, 0, 0, 0};
     std::vector<HostTile> htiles;
+    std::vector<const Component *> big; // components routed to the two-stage path
+    const int two_stage = opt ? opt->two_stage : 0;
     for (const Component &c : comps) {
+        if (two_stage > 0 || (two_stage == 0 && c.rows > kClasses[kNumClasses - 1].tmf * 16)) {
+            big.push_back(&c);
+            continue;
+        }
         // class by shape: columns decide the number of waves, rows the fragment count
         int cls;
         if (opt && opt->tile_n > 0) {
@@ -247,6 +253,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     st.n_tiles = out.tiles.size();
     // work-item size: aim for ~16 items per CU, but never below ~0.5 MMAC-equivalents
     double item_cost = opt && opt->item_macs > 0 ? (double)opt->item_macs : std::max((double)total_cost / 4096.0, 524288.0);
+    const double step_item_cost = opt && opt->item_macs > 0 ? (double)opt->item_macs : 6.0e7;
     uint64_t slab = 0;
     for (size_t t = 0; t < htiles.size(); t++) {
         HostTile &ht = htiles[t];
@@ -288,15 +295,167 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         });
         st.n_items += cw.items.size();
     }
+    // ---- two-stage path: W = alpha X op(Y) to scratch, then psi' tiles += op(Z) W ---------------
+    uint64_t gg_macs = 0;
+    if (!big.empty()) {
+        const int TM = kGGTileM, TN = kGGTileN;
+        const uint64_t budget = (uint64_t)(opt && opt->scratch_mb > 0 ? opt->scratch_mb : 4096) * (1u << 17);
+        // work in component order; a super-step closes when the W scratch budget is reached
+        struct PW {
+            const Component *c;
+            uint32_t wi;
+            uint64_t w_off;
+        };
+        std::vector<PW> cur;
+        uint64_t used = 0;
+        auto flush = [&]() {
+            if (cur.empty())
+                return;
+            SuperStep ss{};
+            ss.s0_begin = (uint32_t)out.gitems.size();
+            // stage 0: tiles of every W
+            for (const PW &pw : cur) {
+                const b2x_pair &p = pairs[win[pw.wi].pair];
+                std::vector<int> rc = balanced_cuts(p.k1, TM), cc = balanced_cuts(p.n0, TN);
+                for (size_t a = 0; a + 1 < rc.size(); a++)
+                    for (size_t b = 0; b + 1 < cc.size(); b++) {
+                        GSeg g{};
+                        g.a_src = 1, g.a_off = p.x_off + (uint64_t)rc[a] * p.lda0, g.a_sr = p.lda0, g.a_sk = 1;
+                        g.b_src = 0;
+                        if (p.tb0)
+                            g.b_off = p.y_off + (uint64_t)cc[b] * p.ldb0, g.b_sk = 1, g.b_sc = p.ldb0;
+                        else
+                            g.b_off = p.y_off + (uint64_t)cc[b], g.b_sk = p.ldb0, g.b_sc = 1;
+                        g.K = p.k0;
+                        g.mr = (int16_t)(rc[a + 1] - rc[a]), g.nc = (int16_t)(cc[b + 1] - cc[b]);
+                        GItem it{};
+                        it.seg_begin = (uint32_t)out.gsegs.size(), it.seg_end = it.seg_begin + 1;
+                        it.out_off = pw.w_off + (uint64_t)rc[a] * p.n0 + cc[b], it.out_ld = p.n0;
+                        it.rows = g.mr, it.cols = g.nc, it.alpha = p.alpha0 * p.alpha1, it.out_kind = 1;
+                        out.gsegs.push_back(g);
+                        out.gitems.push_back(it);
+                        gg_macs += (uint64_t)g.mr * g.nc * g.K;
+                    }
+            }
+            ss.s0_end = ss.s1_begin = (uint32_t)out.gitems.size();
+            ss.tile_begin = (uint32_t)out.gtiles.size();
+            // stage 1: per component, per psi' tile, the segments of this step's pairs
+            uint64_t slab = 0;
+            size_t i = 0;
+            while (i < cur.size()) {
+                size_t j = i;
+                while (j < cur.size() && cur[j].c == cur[i].c)
+                    j++;
+                const Component &c = *cur[i].c;
+                std::vector<int> rc = balanced_cuts(c.rows, TM), cc = balanced_cuts(c.cols, TN);
+                int nrt = (int)rc.size() - 1, nct = (int)cc.size() - 1;
+                std::vector<std::vector<GSeg>> tsegs((size_t)nrt * nct);
+                std::vector<double> tcost((size_t)nrt * nct, 0.0);
+                for (size_t q = i; q < j; q++) {
+                    const Window &w = win[cur[q].wi];
+                    const b2x_pair &p = pairs[w.pair];
+                    uint64_t rel = w.off - c.base;
+                    int row0 = (int)(rel / (uint64_t)c.ld), col0 = (int)(rel % (uint64_t)c.ld);
+                    int a0 = (int)(std::upper_bound(rc.begin(), rc.end(), row0) - rc.begin()) - 1;
+                    int b0 = (int)(std::upper_bound(cc.begin(), cc.end(), col0) - cc.begin()) - 1;
+                    for (int a = a0; a < nrt && rc[a] < row0 + w.m; a++)
+                        for (int b = b0; b < nct && cc[b] < col0 + w.n; b++) {
+                            int ra = std::max(row0, rc[a]), rb = std::min(row0 + w.m, rc[a + 1]);
+                            int ca = std::max(col0, cc[b]), cb = std::min(col0 + w.n, cc[b + 1]);
+                            int r_lo = ra - row0, c_lo = ca - col0;
+                            GSeg g{};
+                            g.a_src = 0;
+                            if (p.ta1)
+                                g.a_off = p.z_off + (uint64_t)r_lo, g.a_sr = 1, g.a_sk = p.lda1;
+                            else
+                                g.a_off = p.z_off + (uint64_t)r_lo * p.lda1, g.a_sr = p.lda1, g.a_sk = 1;
+                            g.b_src = 2, g.b_off = cur[q].w_off + (uint64_t)c_lo, g.b_sk = p.n0, g.b_sc = 1;
+                            g.K = p.k1;
+                            g.mr = (int16_t)(rb - ra), g.nc = (int16_t)(cb - ca);
+                            g.tr0 = (int16_t)(ra - rc[a]), g.tc0 = (int16_t)(ca - cc[b]);
+                            size_t t = (size_t)a * nct + b;
+                            tsegs[t].push_back(g);
+                            tcost[t] += (double)round_up(g.mr, 16) * round_up(g.nc, 16) * round_up(g.K, 16) + 65536.0;
+                            gg_macs += (uint64_t)g.mr * g.nc * g.K;
+                        }
+                }
+                double comp_cost = std::accumulate(tcost.begin(), tcost.end(), 0.0);
+                (void)comp_cost;
+                for (int a = 0; a < nrt; a++)
+                    for (int b = 0; b < nct; b++) {
+                        size_t t = (size_t)a * nct + b;
+                        if (tsegs[t].empty())
+                            continue;
+                        DTile dt{};
+                        dt.sigma_off = c.base + (uint64_t)rc[a] * c.ld + cc[b];
+                        dt.ld = c.ld, dt.rows = rc[a + 1] - rc[a], dt.cols = cc[b + 1] - cc[b];
+                        dt.slab_off = slab;
+                        // items of ~equal cost; target: a few thousand items per super-step
+                        double per_item = step_item_cost;
+                        int n_it = std::max(1, (int)std::lround(tcost[t] / per_item));
+                        double per = tcost[t] / n_it, acc = 0;
+                        int made = 0;
+                        uint32_t begin = (uint32_t)out.gsegs.size();
+                        for (size_t k = 0; k < tsegs[t].size(); k++) {
+                            const GSeg &g = tsegs[t][k];
+                            out.gsegs.push_back(g);
+                            acc += (double)round_up(g.mr, 16) * round_up(g.nc, 16) * round_up(g.K, 16) + 65536.0;
+                            bool last = k + 1 == tsegs[t].size();
+                            if (last || (acc >= per * (made + 1) && made + 1 < n_it)) {
+                                GItem it{};
+                                it.seg_begin = begin, it.seg_end = (uint32_t)out.gsegs.size();
+                                it.out_off = slab, it.out_ld = dt.cols, it.rows = dt.rows, it.cols = dt.cols;
+                                it.alpha = 1.0, it.out_kind = 0;
+                                out.gitems.push_back(it);
+                                slab += (uint64_t)dt.rows * dt.cols;
+                                begin = it.seg_end;
+                                made++;
+                            }
+                        }
+                        dt.n_items = made;
+                        out.gtiles.push_back(dt);
+                    }
+                i = j;
+            }
+            ss.s1_end = (uint32_t)out.gitems.size();
+            ss.tile_end = (uint32_t)out.gtiles.size();
+            // longest stage-1 items first
+            std::stable_sort(out.gitems.begin() + ss.s1_begin, out.gitems.begin() + ss.s1_end,
+                             [&](const GItem &x, const GItem &y) {
+                                 return (x.seg_end - x.seg_begin) > (y.seg_end - y.seg_begin);
+                             });
+            out.steps.push_back(ss);
+            out.scratch_elems = std::max(out.scratch_elems, used);
+            out.gslab_elems = std::max(out.gslab_elems, slab);
+            cur.clear();
+            used = 0;
+        };
+        for (const Component *c : big)
+            for (uint32_t wi = c->w_begin; wi < c->w_end; wi++) {
+                const b2x_pair &p = pairs[win[wi].pair];
+                uint64_t wsz = ((uint64_t)p.k1 * p.n0 + 1) & ~(uint64_t)1;
+                if (used + wsz > budget && !cur.empty())
+                    flush();
+                cur.push_back(PW{c, wi, used});
+                used += wsz;
+            }
+        flush();
+        st.n_tiles += out.gtiles.size();
+        st.n_items += out.gitems.size();
+        st.n_parts += out.gsegs.size();
+    }
     for (int k = 0; k < kNumClasses; k++) {
         out.cls_macs[k] = cls_macs[k];
         if (cls_macs[k] > cls_macs[st.dominant_class])
             st.dominant_class = k;
     }
-    st.macs_executed = cls_macs[0] + cls_macs[1] + cls_macs[2] + cls_macs[3];
+    st.macs_executed = cls_macs[0] + cls_macs[1] + cls_macs[2] + cls_macs[3] + gg_macs;
     st.macs_dominant = cls_macs[st.dominant_class];
     st.macs_alg_dominant = (uint64_t)(cls_alg[st.dominant_class] + 0.5);
-    st.device_bytes = slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
+    if (gg_macs > st.macs_dominant) // the two-stage grouped-GEMM kernel carries the plan
+        st.dominant_class = kNumClasses, st.macs_dominant = gg_macs, st.macs_alg_dominant = gg_macs;
+    st.device_bytes = (out.scratch_elems + out.gslab_elems) * 8 + out.gsegs.size() * sizeof(GSeg) +
+                      out.gitems.size() * sizeof(GItem) + out.gtiles.size() * sizeof(DTile) + slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
     return B2X_OK;
 }
 
@@ -327,6 +486,44 @@ void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double
                     }
             }
             (void)TN;
+        }
+    }
+    // two-stage path
+    std::vector<double> scratch(cp.scratch_elems, 0.0), gslabs(cp.gslab_elems, 0.0);
+    auto run_item = [&](const GItem &it) {
+        std::vector<double> acc((size_t)it.rows * it.cols, 0.0);
+        for (uint32_t si = it.seg_begin; si < it.seg_end; si++) {
+            const GSeg &g = cp.gsegs[si];
+            const double *A = g.a_src == 0 ? arena : (g.a_src == 1 ? psi : scratch.data());
+            const double *B = g.b_src == 0 ? arena : (g.b_src == 1 ? psi : scratch.data());
+            for (int r = 0; r < g.mr; r++)
+                for (int c = 0; c < g.nc; c++) {
+                    double s = 0;
+                    for (int k = 0; k < g.K; k++)
+                        s += A[g.a_off + (uint64_t)r * g.a_sr + (uint64_t)k * g.a_sk] *
+                             B[g.b_off + (uint64_t)k * g.b_sk + (uint64_t)c * g.b_sc];
+                    acc[(size_t)(g.tr0 + r) * it.cols + g.tc0 + c] += s;
+                }
+        }
+        double *o = (it.out_kind ? scratch.data() : gslabs.data()) + it.out_off;
+        for (int r = 0; r < it.rows; r++)
+            for (int c = 0; c < it.cols; c++)
+                o[(size_t)r * it.out_ld + c] = it.alpha * acc[(size_t)r * it.cols + c];
+    };
+    for (const SuperStep &ss : cp.steps) {
+        for (uint32_t i = ss.s0_begin; i < ss.s0_end; i++)
+            run_item(cp.gitems[i]);
+        for (uint32_t i = ss.s1_begin; i < ss.s1_end; i++)
+            run_item(cp.gitems[i]);
+        for (uint32_t ti = ss.tile_begin; ti < ss.tile_end; ti++) {
+            const DTile &t = cp.gtiles[ti];
+            for (int r = 0; r < t.rows; r++)
+                for (int c = 0; c < t.cols; c++) {
+                    double s = 0;
+                    for (int i = 0; i < t.n_items; i++)
+                        s += gslabs[t.slab_off + (uint64_t)i * t.rows * t.cols + (uint64_t)r * t.cols + c];
+                    sigma[t.sigma_off + (uint64_t)r * t.ld + c] += scale * s;
+                }
         }
     }
     for (const DTile &t : cp.tiles)

@@ -46,6 +46,37 @@ struct DTile {
 };
 static_assert(sizeof(DTile) == 32, "DTile layout");
 
+// ---- two-stage path (large sectors): both stages are plain grouped GEMMs -------------------------
+// One K-segment of a tile's accumulation:  C[tr0:tr0+mr, tc0:tc0+nc] += A(mr x K) * B(K x nc)
+struct GSeg {
+    uint64_t a_off, b_off; // element offsets into the buffer selected by a_src / b_src
+    int32_t a_sr, a_sk;    // A[r][k] = bufA[a_off + r*a_sr + k*a_sk]
+    int32_t b_sk, b_sc;    // B[k][c] = bufB[b_off + k*b_sk + c*b_sc]
+    int32_t K;
+    int16_t mr, nc, tr0, tc0;
+    uint8_t a_src, b_src; // 0 = operator arena, 1 = psi, 2 = W scratch
+    uint8_t pad[2];
+};
+static_assert(sizeof(GSeg) == 48, "GSeg layout");
+
+struct GItem {
+    uint32_t seg_begin, seg_end;
+    uint64_t out_off; // element offset in the slab buffer (out_kind 0) or the W scratch (out_kind 1)
+    double alpha;     // factor applied when the tile is stored
+    int32_t out_ld, rows, cols;
+    uint32_t out_kind;
+};
+static_assert(sizeof(GItem) == 40, "GItem layout");
+
+// stage 0 of a batch of pairs -> W scratch; stage 1 consumes it; reduce adds the slabs into psi'
+struct SuperStep {
+    uint32_t s0_begin, s0_end; // GItem ranges
+    uint32_t s1_begin, s1_end;
+    uint32_t tile_begin, tile_end; // DTile range (two-stage tile list)
+};
+
+static const int kGGTileM = 256, kGGTileN = 128;
+
 // kernel classes: NW waves (16 output columns each), TMF row fragments, K1F k1 fragments
 struct KClass {
     int nw, tmf, k1f;
@@ -64,6 +95,12 @@ struct CompiledPlan {
     uint64_t slab_elems = 0;
     uint64_t cls_macs[kNumClasses] = {0, 0, 0, 0}; // MACs the kernels of each class execute
     b2x_plan_stats stats{};
+    // two-stage path
+    std::vector<GSeg> gsegs;
+    std::vector<GItem> gitems;
+    std::vector<DTile> gtiles;
+    std::vector<SuperStep> steps;
+    uint64_t scratch_elems = 0, gslab_elems = 0;
     bool fallback = false; // windows could not be segmented -> generic atomic kernel
     std::string fallback_reason;
 };

@@ -112,3 +112,35 @@ def test_config1_scale_h10_m500(gpu):
     oracle.replay(big.pairs, big.arena, big.psi, ref, 1.0, 8)
     sig, st = _run(gpu, big)
     assert _close(sig, ref), st
+
+
+@pytest.mark.parametrize("fn", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_golden_two_stage_path(gpu, fn):
+    """the grouped-GEMM (two-stage, W through scratch) path on the reference's golden plans"""
+    pf = read_plan(fn)
+    sig, st = _run(gpu, pf, two_stage=1)
+    assert st["dominant_class"] == 4 and st["macs_executed"] == st["macs"]
+    assert _close(sig, pf.sigma_ref)
+
+
+@pytest.mark.parametrize("seed,scratch_mb,item_macs", [(0, 0, 0), (1, 1, 0), (2, 1, 200000), (3, 2, 1 << 40)])
+def test_two_stage_random_multi_superstep(gpu, seed, scratch_mb, item_macs):
+    """several super-steps (1-2 MiB of W scratch), several items per tile, row/col slices, tiles > 256 rows"""
+    rng = np.random.default_rng(300 + seed)
+    pf = fill_plan(synth.random_rotate_plan(rng, n_sectors=3, max_dim=420, max_terms=5), seed)
+    ref = np.zeros(pf.sigma_len)
+    oracle.replay(pf.pairs, pf.arena, pf.psi, ref, 1.0, 8)
+    sig, st = _run(gpu, pf, two_stage=1, scratch_mb=scratch_mb, item_macs=item_macs)
+    assert _close(sig, ref), st
+    again, _ = _run(gpu, pf, two_stage=1, scratch_mb=scratch_mb, item_macs=item_macs)
+    assert np.array_equal(again, sig)
+
+
+def test_auto_routing_mixed_paths(gpu):
+    """auto mode: sectors taller than one fused tile go two-stage, the rest stay fused — same answer"""
+    pf = read_plan([f for f in FILES if "h10szm50.sw2.site4" in f][0])
+    big = fill_plan(synth.scale_plan(pf, 8), 4)
+    ref = np.zeros(big.sigma_len)
+    oracle.replay(big.pairs, big.arena, big.psi, ref, 1.0, 8)
+    sig, st = _run(gpu, big)
+    assert _close(sig, ref), st

@@ -68,3 +68,16 @@ def test_empty_and_invalid(built):
     bad["ta0"] = 1  # unsupported on this path
     with pytest.raises(capi.B2XError):
         capi.debug_compile_and_emulate(bad, 16, 16, np.zeros(32), np.zeros(16), np.zeros(16))
+
+
+@pytest.mark.parametrize("fn", FILES[:3], ids=[os.path.basename(f) for f in FILES[:3]])
+def test_compiled_two_stage_golden(built, fn):
+    st = _check(read_plan(fn), two_stage=1)
+    assert st["dominant_class"] == 4 and st["macs_executed"] == st["macs"]  # no recomputation on this path
+
+
+@pytest.mark.parametrize("scratch_mb,item_macs", [(1, 0), (1, 100000), (3, 1 << 40)])
+def test_compiled_two_stage_multi_superstep(built, scratch_mb, item_macs):
+    rng = np.random.default_rng(17)
+    pf = fill_plan(synth.random_rotate_plan(rng, n_sectors=3, max_dim=400, max_terms=4), 17)
+    _check(pf, two_stage=1, scratch_mb=scratch_mb, item_macs=item_macs)
