@@ -48,7 +48,7 @@ __global__ __launch_bounds__(NW * 64) void hpsi_main(const DPart *__restrict__ p
         const int cabs = wave * 16 + c;
         const bool col_ok = cabs >= tc0 && cabs < tc0 + nc;
         const bool wave_on = (wave * 16 + 16 > tc0) && (wave * 16 < tc0 + nc);
-        const double *yp = arena + P.y_off + (int64_t)(cabs - tc0) * P.scy;
+        const double *ypc = arena + P.y_off + (int64_t)min(max(cabs - tc0, 0), nc - 1) * P.scy; // clamped column
         const int f_lo = tr0 >> 4, f_hi = (tr0 + mr + 15) >> 4; // row fragments touched by this part
         const bool zt = (P.srz == 1 && P.skz != 1);             // op(Z) stored k-major (transposed block)
         const int lsr = zt ? 1 : LDX, lsk = zt ? LDZT : 1;
@@ -68,16 +68,15 @@ __global__ __launch_bounds__(NW * 64) void hpsi_main(const DPart *__restrict__ p
                 __syncthreads(); // readers of the previous Xs / Zs chunk are done
                 for (int idx = tid; idx < K1C * 16; idx += NT) {
                     int row = idx >> 4, kk = idx & 15;
-                    double v = 0.0;
-                    if (row < k1c && kb + kk < k0)
-                        v = xp[(int64_t)row * P.ldx + kb + kk];
-                    Xs[row * LDX + kk] = v;
+                    double v = xp[(int64_t)min(row, k1c - 1) * P.ldx + min(kb + kk, k0 - 1)];
+                    Xs[row * LDX + kk] = (row < k1c && kb + kk < k0) ? v : 0.0;
                 }
                 double b[4];
 #pragma unroll
                 for (int s = 0; s < 4; s++) {
                     int k = kb + 4 * s + g;
-                    b[s] = (col_ok && k < k0) ? yp[(int64_t)k * P.sky] : 0.0;
+                    double v = ypc[(int64_t)min(k, k0 - 1) * P.sky];
+                    b[s] = v * ((col_ok && k < k0) ? 1.0 : 0.0); // mask-multiply keeps the load unconditional
                 }
                 __syncthreads();
                 if (wave_on) {
@@ -107,19 +106,16 @@ __global__ __launch_bounds__(NW * 64) void hpsi_main(const DPart *__restrict__ p
                         for (int idx = tid; idx < n_rows * 16; idx += NT) {
                             int row = r_lo + (idx >> 4), kk = idx & 15;
                             int rr = row - tr0;
-                            double v = 0.0;
-                            if (rr >= 0 && rr < mr && kc + kk < k1c)
-                                v = zp[(int64_t)rr * P.srz + (int64_t)(kc + kk) * P.skz];
-                            Zs[row * LDX + kk] = v;
+                            double v = zp[(int64_t)min(max(rr, 0), mr - 1) * P.srz +
+                                          (int64_t)min(kc + kk, k1c - 1) * P.skz];
+                            Zs[row * LDX + kk] = (rr >= 0 && rr < mr && kc + kk < k1c) ? v : 0.0;
                         }
                     } else {
                         for (int idx = tid; idx < n_rows * 16; idx += NT) {
                             int kk = idx / n_rows, row = r_lo + idx % n_rows;
                             int rr = row - tr0;
-                            double v = 0.0;
-                            if (rr >= 0 && rr < mr && kc + kk < k1c)
-                                v = zp[(int64_t)rr + (int64_t)(kc + kk) * P.skz];
-                            Zs[kk * LDZT + row] = v;
+                            double v = zp[(int64_t)min(max(rr, 0), mr - 1) + (int64_t)min(kc + kk, k1c - 1) * P.skz];
+                            Zs[kk * LDZT + row] = (rr >= 0 && rr < mr && kc + kk < k1c) ? v : 0.0;
                         }
                     }
                     __syncthreads();
@@ -187,50 +183,60 @@ __global__ __launch_bounds__(256, 1) void gg_kernel(const GSeg *__restrict__ seg
 
     double areg[NA];
     double bnxt[CF][4], bcur[CF][4];
+    uint32_t amask = 0, bmask = 0; // validity bits of the chunk in flight (applied when it is committed)
 
-    // issue the global loads of one 16-k chunk of segment S at k offset kb
+    // Issue the global loads of one 16-k chunk of segment S at k offset kb.  Loads are unconditional, from
+    // clamped (always valid) addresses; validity is recorded as bit masks and applied in commit().  A
+    // branch or a select next to the load makes hipcc wait for the data right here (vmcnt(0) per element),
+    // which would serialize the chunk instead of overlapping it with the MFMAs of the current chunk.
     auto fetch = [&](const GSeg &S, int kb) {
         const double *A = (S.a_src == 0 ? arena : (S.a_src == 1 ? psi : scratch)) + S.a_off;
         const double *B = (S.b_src == 0 ? arena : (S.b_src == 1 ? psi : scratch)) + S.b_off;
         const bool kmaj = (S.a_sk != 1); // A stored with the row index contiguous
+        amask = 0, bmask = 0;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             int e = tid + 256 * i;
             int row = kmaj ? (e % TM) : (e >> 4);
             int kk = kmaj ? (e / TM) : (e & 15);
             int rr = row - S.tr0;
-            double v = 0.0;
-            if (rr >= 0 && rr < S.mr && kb + kk < S.K)
-                v = A[(int64_t)rr * S.a_sr + (int64_t)(kb + kk) * S.a_sk];
-            areg[i] = v;
+            amask |= (uint32_t)(rr >= 0 && rr < S.mr && kb + kk < S.K) << i;
+            int rc_ = min(max(rr, 0), S.mr - 1), kc_ = min(kb + kk, S.K - 1);
+            areg[i] = A[(int64_t)rc_ * S.a_sr + (int64_t)kc_ * S.a_sk];
         }
 #pragma unroll
         for (int q = 0; q < CF; q++) {
             int cc = wave * (CF * 16) + q * 16 + c - S.tc0;
-            bool ok = cc >= 0 && cc < S.nc;
+            const bool ok = cc >= 0 && cc < S.nc;
+            const int ccl = min(max(cc, 0), S.nc - 1);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 int k = kb + 4 * s + g;
-                bnxt[q][s] = (ok && k < S.K) ? B[(int64_t)k * S.b_sk + (int64_t)cc * S.b_sc] : 0.0;
+                bmask |= (uint32_t)(ok && k < S.K) << (q * 4 + s);
+                bnxt[q][s] = B[(int64_t)min(k, S.K - 1) * S.b_sk + (int64_t)ccl * S.b_sc];
             }
         }
     };
-    // registers -> LDS buffer
+    // registers -> LDS buffer (A) / current B fragments, invalid elements zeroed
     auto commit = [&](const GSeg &S, double *As) {
-        const bool kmaj = (S.a_sk != 1);
+        if (S.a_sk != 1) {
 #pragma unroll
-        for (int i = 0; i < NA; i++) {
-            int e = tid + 256 * i;
-            if (kmaj)
-                As[(e / TM) * LDZT + (e % TM)] = areg[i];
-            else
-                As[(e >> 4) * LDX + (e & 15)] = areg[i];
+            for (int i = 0; i < NA; i++) {
+                int e = tid + 256 * i;
+                As[(e / TM) * LDZT + (e % TM)] = ((amask >> i) & 1) ? areg[i] : 0.0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                int e = tid + 256 * i;
+                As[(e >> 4) * LDX + (e & 15)] = ((amask >> i) & 1) ? areg[i] : 0.0;
+            }
         }
 #pragma unroll
         for (int q = 0; q < CF; q++)
 #pragma unroll
             for (int s = 0; s < 4; s++)
-                bcur[q][s] = bnxt[q][s];
+                bcur[q][s] = ((bmask >> (q * 4 + s)) & 1) ? bnxt[q][s] : 0.0;
     };
 
     uint32_t si = item.seg_begin;
@@ -252,31 +258,26 @@ __global__ __launch_bounds__(256, 1) void gg_kernel(const GSeg *__restrict__ seg
                 Sn = segs[nsi];
             if (more)
                 fetch(Sn, nkb);
+            __builtin_amdgcn_sched_barrier(0); // loads issued; nothing below may move above them
             // ---- compute the chunk resident in LDS ----
             {
                 const double *As = lds + buf * ABUF;
                 const bool kmaj = (S.a_sk != 1);
                 const int lsr = kmaj ? 1 : LDX, lsk = kmaj ? LDZT : 1;
                 const int f_lo = S.tr0 >> 4, f_hi = (S.tr0 + S.mr + 15) >> 4;
-                bool qon[CF];
 #pragma unroll
-                for (int q = 0; q < CF; q++) {
-                    int c0 = wave * (CF * 16) + q * 16;
-                    qon[q] = (c0 + 16 > S.tc0) && (c0 < S.tc0 + S.nc);
-                }
+                for (int f = 0; f < TMF; f++)
+                    if (f >= f_lo && f < f_hi) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-#pragma unroll
-                    for (int f = 0; f < TMF; f++)
-                        if (f >= f_lo && f < f_hi) {
+                        for (int s = 0; s < 4; s++) {
                             double a = As[(f * 16 + c) * lsr + (4 * s + g) * lsk];
 #pragma unroll
                             for (int q = 0; q < CF; q++)
-                                if (qon[q])
-                                    acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][s], acc[f][q], 0, 0, 0);
+                                acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][s], acc[f][q], 0, 0, 0);
                         }
-                }
+                    }
             }
+            __builtin_amdgcn_sched_barrier(0); // the prefetched chunk is consumed only after the MFMAs
             if (!more)
                 break;
             buf ^= 1;

@@ -170,7 +170,13 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     std::vector<const Component *> big; // components routed to the two-stage path
     const int two_stage = opt ? opt->two_stage : 0;
     for (const Component &c : comps) {
-        if (two_stage > 0 || (two_stage == 0 && c.rows > kClasses[kNumClasses - 1].tmf * 16)) {
+        // auto routing: the fused kernel recomputes stage 0 per row tile and keeps W in registers, which
+        // pays for sectors that fit one tile; tall / wide / deep ones go to the grouped-GEMM path
+        int max_k0 = 0;
+        for (uint32_t wi = c.w_begin; wi < c.w_end; wi++)
+            max_k0 = std::max(max_k0, (int)pairs[win[wi].pair].k0);
+        const bool large = c.rows > kClasses[kNumClasses - 1].tmf * 16 || c.cols > 128 || max_k0 > 512;
+        if (two_stage > 0 || (two_stage == 0 && large)) {
             big.push_back(&c);
             continue;
         }
@@ -327,7 +333,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         else
                             g.b_off = p.y_off + (uint64_t)cc[b], g.b_sk = p.ldb0, g.b_sc = 1;
                         g.K = p.k0;
-                        g.mr = (int16_t)(rc[a + 1] - rc[a]), g.nc = (int16_t)(cc[b + 1] - cc[b]);
+                        g.mr = rc[a + 1] - rc[a], g.nc = cc[b + 1] - cc[b];
                         GItem it{};
                         it.seg_begin = (uint32_t)out.gsegs.size(), it.seg_end = it.seg_begin + 1;
                         it.out_off = pw.w_off + (uint64_t)rc[a] * p.n0 + cc[b], it.out_ld = p.n0;
@@ -371,8 +377,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                                 g.a_off = p.z_off + (uint64_t)r_lo * p.lda1, g.a_sr = p.lda1, g.a_sk = 1;
                             g.b_src = 2, g.b_off = cur[q].w_off + (uint64_t)c_lo, g.b_sk = p.n0, g.b_sc = 1;
                             g.K = p.k1;
-                            g.mr = (int16_t)(rb - ra), g.nc = (int16_t)(cb - ca);
-                            g.tr0 = (int16_t)(ra - rc[a]), g.tc0 = (int16_t)(ca - cc[b]);
+                            g.mr = rb - ra, g.nc = cb - ca;
+                            g.tr0 = ra - rc[a], g.tc0 = ca - cc[b];
                             size_t t = (size_t)a * nct + b;
                             tsegs[t].push_back(g);
                             tcost[t] += (double)round_up(g.mr, 16) * round_up(g.nc, 16) * round_up(g.K, 16) + 65536.0;

@@ -53,11 +53,11 @@ struct GSeg {
     int32_t a_sr, a_sk;    // A[r][k] = bufA[a_off + r*a_sr + k*a_sk]
     int32_t b_sk, b_sc;    // B[k][c] = bufB[b_off + k*b_sk + c*b_sc]
     int32_t K;
-    int16_t mr, nc, tr0, tc0;
-    uint8_t a_src, b_src; // 0 = operator arena, 1 = psi, 2 = W scratch
-    uint8_t pad[2];
+    int32_t mr, nc, tr0, tc0;
+    int32_t a_src, b_src; // 0 = operator arena, 1 = psi, 2 = W scratch
+    int32_t pad;          // all fields 32/64-bit so the descriptor is fetched with scalar loads
 };
-static_assert(sizeof(GSeg) == 48, "GSeg layout");
+static_assert(sizeof(GSeg) == 64, "GSeg layout");
 
 struct GItem {
     uint32_t seg_begin, seg_end;
