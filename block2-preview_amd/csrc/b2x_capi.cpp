@@ -301,10 +301,8 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
         HIPCHK(launch_main(k, p->d_parts[k], p->d_items[k], p->n_items[k], p->arena->dev, psi, p->d_slabs, st));
     HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma, scale, st));
     for (const SuperStep &ss : p->steps) {
-        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems + ss.s0_begin, ss.s0_end - ss.s0_begin, p->arena->dev, psi,
-                         p->d_scratch, p->d_gslabs, st));
-        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems + ss.s1_begin, ss.s1_end - ss.s1_begin, p->arena->dev, psi,
-                         p->d_scratch, p->d_gslabs, st));
+        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, st));
+        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, st));
         HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st));
     }
     return B2X_OK;
@@ -361,10 +359,10 @@ int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, 
             // bracketed together; fused classes + reduces make up the rest of the total
             HIPCHK(hipEventRecord(e0, st));
             for (const SuperStep &ss : p->steps) {
-                HIPCHK(launch_gg(p->d_gsegs, p->d_gitems + ss.s0_begin, ss.s0_end - ss.s0_begin, p->arena->dev,
-                                 psi_dev, p->d_scratch, p->d_gslabs, st));
-                HIPCHK(launch_gg(p->d_gsegs, p->d_gitems + ss.s1_begin, ss.s1_end - ss.s1_begin, p->arena->dev,
-                                 psi_dev, p->d_scratch, p->d_gslabs, st));
+                HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi_dev, p->d_scratch,
+                                 p->d_gslabs, st));
+                HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi_dev, p->d_scratch,
+                                 p->d_gslabs, st));
             }
             HIPCHK(hipEventRecord(e1, st));
             HIPCHK(hipEventSynchronize(e1));

@@ -159,15 +159,16 @@ __global__ __launch_bounds__(NW * 64) void hpsi_main(const DPart *__restrict__ p
 // Wave w owns CF column fragments x all TMF row fragments (acc = TMF*CF*8 VGPRs).  A chunks (16 k)
 // are staged global -> registers -> LDS one chunk ahead (double-buffered LDS, one barrier per chunk);
 // B fragments are private to a wave and are prefetched one chunk ahead straight into registers.
-template <int TMF, int CF>
-__global__ __launch_bounds__(256, 1) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
+template <int TMF, int CF, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
                                                      const double *__restrict__ arena,
                                                      const double *__restrict__ psi, double *__restrict__ scratch,
                                                      double *__restrict__ slabs) {
     constexpr int TM = TMF * 16, LDX = 18;
     constexpr int LDZT = (TM % 32 == 0) ? TM + 16 : TM;
     constexpr int ABUF = (TM * LDX > 16 * LDZT) ? TM * LDX : 16 * LDZT;
-    constexpr int NA = TM * 16 / 256; // A elements staged per thread per chunk
+    constexpr int NT = NW * 64;
+    constexpr int NA = TM * 16 / NT; // A elements staged per thread per chunk
     __shared__ double lds[2 * ABUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256, 1) void gg_kernel(const GSeg *__restrict__ seg
         amask = 0, bmask = 0;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            int e = tid + 256 * i;
+            int e = tid + NT * i;
             int row = kmaj ? (e % TM) : (e >> 4);
             int kk = kmaj ? (e / TM) : (e & 15);
             int rr = row - S.tr0;
@@ -222,13 +223,13 @@ __global__ __launch_bounds__(256, 1) void gg_kernel(const GSeg *__restrict__ seg
         if (S.a_sk != 1) {
 #pragma unroll
             for (int i = 0; i < NA; i++) {
-                int e = tid + 256 * i;
+                int e = tid + NT * i;
                 As[(e / TM) * LDZT + (e % TM)] = ((amask >> i) & 1) ? areg[i] : 0.0;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NA; i++) {
-                int e = tid + 256 * i;
+                int e = tid + NT * i;
                 As[(e >> 4) * LDX + (e & 15)] = ((amask >> i) & 1) ? areg[i] : 0.0;
             }
         }
@@ -264,18 +265,19 @@ __global__ __launch_bounds__(256, 1) void gg_kernel(const GSeg *__restrict__ seg
                 const double *As = lds + buf * ABUF;
                 const bool kmaj = (S.a_sk != 1);
                 const int lsr = kmaj ? 1 : LDX, lsk = kmaj ? LDZT : 1;
-                const int f_lo = S.tr0 >> 4, f_hi = (S.tr0 + S.mr + 15) >> 4;
+                // branch-free: all TMF x CF fragments every chunk (rows/cols outside the segment's window are
+                // zero in LDS / in the B registers).  Any branch here splits the block and makes hipcc shuttle
+                // the accumulators between VGPRs and AGPRs around every fragment group (drains the MFMA pipe).
 #pragma unroll
-                for (int f = 0; f < TMF; f++)
-                    if (f >= f_lo && f < f_hi) {
+                for (int s = 0; s < 4; s++) {
 #pragma unroll
-                        for (int s = 0; s < 4; s++) {
-                            double a = As[(f * 16 + c) * lsr + (4 * s + g) * lsk];
+                    for (int f = 0; f < TMF; f++) {
+                        double a = As[(f * 16 + c) * lsr + (4 * s + g) * lsk];
 #pragma unroll
-                            for (int q = 0; q < CF; q++)
-                                acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][s], acc[f][q], 0, 0, 0);
-                        }
+                        for (int q = 0; q < CF; q++)
+                            acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][s], acc[f][q], 0, 0, 0);
                     }
+                }
             }
             __builtin_amdgcn_sched_barrier(0); // the prefetched chunk is consumed only after the MFMAs
             if (!more)
@@ -311,7 +313,8 @@ __global__ __launch_bounds__(256) void hpsi_reduce(const DTile *__restrict__ til
     const int n = t.rows * t.cols;
     if (t.n_items == 0)
         return;
-    for (int e = threadIdx.x; e < n; e += 256) {
+    // blockIdx.y strides over the tile's elements: enough workgroups to stream the slabs at HBM rate
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < n; e += gridDim.y * 256) {
         const double *s = slabs + t.slab_off + e;
         double sum = 0.0;
         for (int i = 0; i < t.n_items; i++)
@@ -454,12 +457,37 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_gg(const GSeg *segs, const GItem *items, uint32_t n_items, const double *arena, const double *psi,
-                     double *scratch, double *slabs, hipStream_t st) {
-    if (n_items == 0)
-        return hipSuccess;
-    hipLaunchKernelGGL((gg_kernel<kGGTileM / 16, kGGTileN / 64>), dim3(n_items), dim3(256), 0, st, segs, items, arena,
-                       psi, scratch, slabs);
+template <int TMF>
+static void launch_gg_t(const GSeg *segs, const GItem *items, uint32_t n, const double *arena, const double *psi,
+                        double *scratch, double *slabs, hipStream_t st) {
+    // 8 waves x (TMF row fragments x 1 column fragment): <= 128 accumulator VGPRs per wave, 2 waves per SIMD
+    hipLaunchKernelGGL((gg_kernel<TMF, 1, kGGTileN / 16>), dim3(n), dim3(kGGTileN * 4), 0, st, segs, items, arena, psi,
+                       scratch, slabs);
+}
+
+// items are grouped by tile-height variant: v_begin[v] .. v_begin[v+1] use gg_kernel<4*(v+1)>
+hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_begin, const double *arena,
+                     const double *psi, double *scratch, double *slabs, hipStream_t st) {
+    for (int v = 0; v < kGGVariants; v++) {
+        uint32_t n = v_begin[v + 1] - v_begin[v];
+        if (n == 0)
+            continue;
+        const GItem *it = items + v_begin[v];
+        switch (v) {
+        case 0:
+            launch_gg_t<4>(segs, it, n, arena, psi, scratch, slabs, st);
+            break;
+        case 1:
+            launch_gg_t<8>(segs, it, n, arena, psi, scratch, slabs, st);
+            break;
+        case 2:
+            launch_gg_t<12>(segs, it, n, arena, psi, scratch, slabs, st);
+            break;
+        default:
+            launch_gg_t<16>(segs, it, n, arena, psi, scratch, slabs, st);
+            break;
+        }
+    }
     return hipGetLastError();
 }
 
@@ -467,7 +495,7 @@ hipError_t launch_reduce(const DTile *tiles, uint32_t n_tiles, const double *sla
                          hipStream_t st) {
     if (n_tiles == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(hpsi_reduce, dim3(n_tiles), dim3(256), 0, st, tiles, slabs, sigma, scale);
+    hipLaunchKernelGGL(hpsi_reduce, dim3(n_tiles, 16), dim3(256), 0, st, tiles, slabs, sigma, scale);
     return hipGetLastError();
 }
 

@@ -318,7 +318,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             if (cur.empty())
                 return;
             SuperStep ss{};
-            ss.s0_begin = (uint32_t)out.gitems.size();
+            const uint32_t s0_begin = (uint32_t)out.gitems.size();
             // stage 0: tiles of every W
             for (const PW &pw : cur) {
                 const b2x_pair &p = pairs[win[pw.wi].pair];
@@ -343,7 +343,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         gg_macs += (uint64_t)g.mr * g.nc * g.K;
                     }
             }
-            ss.s0_end = ss.s1_begin = (uint32_t)out.gitems.size();
+            const uint32_t s1_begin = (uint32_t)out.gitems.size();
             ss.tile_begin = (uint32_t)out.gtiles.size();
             // stage 1: per component, per psi' tile, the segments of this step's pairs
             uint64_t slab = 0;
@@ -353,7 +353,24 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 while (j < cur.size() && cur[j].c == cur[i].c)
                     j++;
                 const Component &c = *cur[i].c;
-                std::vector<int> rc = balanced_cuts(c.rows, TM), cc = balanced_cuts(c.cols, TN);
+                // rows: cut first at the boundaries of the row slices (three_rotate windows stack the sector
+                // from a few row ranges), then balance each range into tiles; columns: balanced tiles
+                std::vector<int> bounds{0, c.rows};
+                for (size_t q = i; q < j; q++) {
+                    const Window &w = win[cur[q].wi];
+                    int row0 = (int)((w.off - c.base) / (uint64_t)c.ld);
+                    bounds.push_back(row0), bounds.push_back(row0 + w.m);
+                }
+                std::sort(bounds.begin(), bounds.end());
+                bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
+                std::vector<int> rc;
+                for (size_t bi = 0; bi + 1 < bounds.size(); bi++) {
+                    std::vector<int> sub = balanced_cuts(bounds[bi + 1] - bounds[bi], TM);
+                    for (size_t k = 0; k + 1 < sub.size(); k++)
+                        rc.push_back(bounds[bi] + sub[k]);
+                }
+                rc.push_back(c.rows);
+                std::vector<int> cc = balanced_cuts(c.cols, TN);
                 int nrt = (int)rc.size() - 1, nct = (int)cc.size() - 1;
                 std::vector<std::vector<GSeg>> tsegs((size_t)nrt * nct);
                 std::vector<double> tcost((size_t)nrt * nct, 0.0);
@@ -423,13 +440,35 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     }
                 i = j;
             }
-            ss.s1_end = (uint32_t)out.gitems.size();
+            const uint32_t s1_end = (uint32_t)out.gitems.size();
             ss.tile_end = (uint32_t)out.gtiles.size();
-            // longest stage-1 items first
-            std::stable_sort(out.gitems.begin() + ss.s1_begin, out.gitems.begin() + ss.s1_end,
-                             [&](const GItem &x, const GItem &y) {
-                                 return (x.seg_end - x.seg_begin) > (y.seg_end - y.seg_begin);
-                             });
+            // group by tile-height variant; inside a variant, longest items first
+            auto variant = [](const GItem &x) { return std::min(kGGVariants - 1, (x.rows - 1) / 64); };
+            auto order = [&](const GItem &x, const GItem &y) {
+                int vx = variant(x), vy = variant(y);
+                if (vx != vy)
+                    return vx < vy;
+                return (x.seg_end - x.seg_begin) > (y.seg_end - y.seg_begin);
+            };
+            std::stable_sort(out.gitems.begin() + s0_begin, out.gitems.begin() + s1_begin, order);
+            std::stable_sort(out.gitems.begin() + s1_begin, out.gitems.begin() + s1_end, order);
+            auto fill = [&](uint32_t b, uint32_t e, uint32_t *v) {
+                uint32_t pos = b;
+                for (int k = 0; k < kGGVariants; k++) {
+                    v[k] = pos;
+                    while (pos < e && variant(out.gitems[pos]) == k)
+                        pos++;
+                }
+                v[kGGVariants] = e;
+            };
+            fill(s0_begin, s1_begin, ss.s0_v);
+            fill(s1_begin, s1_end, ss.s1_v);
+            for (uint32_t ii = s0_begin; ii < s1_end; ii++) {
+                const GItem &it = out.gitems[ii];
+                uint64_t tm = 64 * (uint64_t)(variant(it) + 1);
+                for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
+                    st.macs_issued += tm * TN * (uint64_t)round_up(out.gsegs[k].K, 16);
+            }
             out.steps.push_back(ss);
             out.scratch_elems = std::max(out.scratch_elems, used);
             out.gslab_elems = std::max(out.gslab_elems, slab);
@@ -517,9 +556,9 @@ void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double
                 o[(size_t)r * it.out_ld + c] = it.alpha * acc[(size_t)r * it.cols + c];
     };
     for (const SuperStep &ss : cp.steps) {
-        for (uint32_t i = ss.s0_begin; i < ss.s0_end; i++)
+        for (uint32_t i = ss.s0_v[0]; i < ss.s0_v[kGGVariants]; i++)
             run_item(cp.gitems[i]);
-        for (uint32_t i = ss.s1_begin; i < ss.s1_end; i++)
+        for (uint32_t i = ss.s1_v[0]; i < ss.s1_v[kGGVariants]; i++)
             run_item(cp.gitems[i]);
         for (uint32_t ti = ss.tile_begin; ti < ss.tile_end; ti++) {
             const DTile &t = cp.gtiles[ti];

@@ -68,10 +68,13 @@ struct GItem {
 };
 static_assert(sizeof(GItem) == 40, "GItem layout");
 
-// stage 0 of a batch of pairs -> W scratch; stage 1 consumes it; reduce adds the slabs into psi'
+// stage 0 of a batch of pairs -> W scratch; stage 1 consumes it; reduce adds the slabs into psi'.
+// Items are grouped by tile-height variant v (tile rows <= 64*(v+1)): variant v of stage s is the GItem
+// range [s?_v[v], s?_v[v+1]) and is launched with gg_kernel<4*(v+1), ...>.
+static const int kGGVariants = 4;
 struct SuperStep {
-    uint32_t s0_begin, s0_end; // GItem ranges
-    uint32_t s1_begin, s1_end;
+    uint32_t s0_v[kGGVariants + 1];
+    uint32_t s1_v[kGGVariants + 1];
     uint32_t tile_begin, tile_end; // DTile range (two-stage tile list)
 };
 
