@@ -30,7 +30,7 @@ class PlanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_pairs", "macs", "op_elems_unique", "psi_len", "sigma_len", "n_targets", "n_tiles", "n_items",
         "n_parts", "device_bytes", "macs_executed", "dominant_class", "macs_dominant",
-        "macs_alg_dominant", "macs_issued")]
+        "macs_alg_dominant", "n_launches", "macs_issued")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}

@@ -497,8 +497,14 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     st.macs_executed = cls_macs[0] + cls_macs[1] + cls_macs[2] + cls_macs[3] + gg_macs;
     st.macs_dominant = cls_macs[st.dominant_class];
     st.macs_alg_dominant = (uint64_t)(cls_alg[st.dominant_class] + 0.5);
-    if (gg_macs > st.macs_dominant) // the two-stage grouped-GEMM kernel carries the plan
+    st.n_launches = 1;
+    if (gg_macs > st.macs_dominant) { // the two-stage grouped-GEMM kernel carries the plan
         st.dominant_class = kNumClasses, st.macs_dominant = gg_macs, st.macs_alg_dominant = gg_macs;
+        st.n_launches = 0;
+        for (const SuperStep &ss : out.steps)
+            for (int v = 0; v < kGGVariants; v++)
+                st.n_launches += (ss.s0_v[v + 1] > ss.s0_v[v]) + (ss.s1_v[v + 1] > ss.s1_v[v]);
+    }
     st.device_bytes = (out.scratch_elems + out.gslab_elems) * 8 + out.gsegs.size() * sizeof(GSeg) +
                       out.gitems.size() * sizeof(GItem) + out.gtiles.size() * sizeof(DTile) + slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
     return B2X_OK;

@@ -80,6 +80,7 @@ typedef struct b2x_plan_stats {
     uint64_t dominant_class;  /* kernel class that carries most MACs */
     uint64_t macs_dominant;   /* MACs executed by the dominant class */
     uint64_t macs_alg_dominant; /* algorithmic (reference-count) MACs of the pairs in the dominant class */
+    uint64_t n_launches;      /* launches of the dominant kernel per execute */
     uint64_t macs_issued;     /* MFMA issue slots x 1024 of the two-stage path incl. tile padding (0 if unused) */
 } b2x_plan_stats;
 
