@@ -136,12 +136,19 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("launch with --nproc-per-node equal to --gpus")
     log = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
+    ndev = torch.cuda.device_count()
+    if local >= ndev:  # rehearsal of the N>1 path on a 1-GPU box (B2X_DIST_BACKEND=gloo): ranks share the card
+        local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("B2X_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     from block2_preview_amd import capi, synth
     from block2_preview_amd.planfile import read_struct_npz
 

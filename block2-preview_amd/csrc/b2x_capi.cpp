@@ -452,6 +452,10 @@ int b2x_vec_precondition(double *q, const double *diag, double shift, size_t n, 
     HIPCHK(launch_precond(q, diag, shift, n, (hipStream_t)stream));
     return B2X_OK;
 }
+int b2x_vec_olsen_prepare(double *q, double *t, const double *c, const double *diag, double ld, size_t n, void *stream) {
+    HIPCHK(launch_olsen(q, t, c, diag, ld, n, (hipStream_t)stream));
+    return B2X_OK;
+}
 int b2x_vec_lincomb(const double *const *vs, int nv, const double *coef, double *y, size_t n, void *stream) {
     if (nv < 1 || nv > 64)
         return fail(B2X_ERR_INVALID, "b2x_vec_lincomb: need 1 <= nv <= 64");

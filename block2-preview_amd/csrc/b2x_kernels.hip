@@ -383,6 +383,14 @@ __global__ void vec_precond_k(double *q, const double *diag, double shift, size_
             q[i] /= d;
     }
 }
+__global__ void vec_olsen_k(double *q, double *t, const double *c, const double *diag, double ld, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double d = ld - diag[i], tv = c[i], qv = q[i];
+        if (fabs(d) > 1e-12)
+            tv /= d, qv /= d;
+        t[i] = tv, q[i] = qv;
+    }
+}
 struct VecPtrs {
     const double *p[64];
     double coef[64];
@@ -521,6 +529,10 @@ hipError_t launch_scal(double a, double *x, size_t n, hipStream_t st) {
 }
 hipError_t launch_precond(double *q, const double *diag, double shift, size_t n, hipStream_t st) {
     hipLaunchKernelGGL(vec_precond_k, dim3(vec_grid(n)), dim3(256), 0, st, q, diag, shift, n);
+    return hipGetLastError();
+}
+hipError_t launch_olsen(double *q, double *t, const double *c, const double *diag, double ld, size_t n, hipStream_t st) {
+    hipLaunchKernelGGL(vec_olsen_k, dim3(vec_grid(n)), dim3(256), 0, st, q, t, c, diag, ld, n);
     return hipGetLastError();
 }
 hipError_t launch_lincomb(const double *const *vs, const double *coef, int nv, double *y, size_t n, hipStream_t st) {

@@ -1,0 +1,418 @@
+// b2x_host.hpp — C++ host-side mirror of block2's interface for the H·psi path, above the C ABI.
+//
+// Same names, argument meaning and error behaviour as the reference classes this path sits behind, so a
+// block2 user (and the parity tests) can drive the MI355X path the way they drive block2:
+//
+//   GMatrix                      src/core/matrix.hpp:92-107          row-major view {data, m, n}
+//   SeqTypes                     src/core/threading.hpp:105-135
+//   BatchGEMMSeq::rotate         src/core/batch_gemm.hpp:893-902     records one GEMM pair
+//   BatchGEMMSeq::three_rotate   src/core/batch_gemm.hpp:952-1022    records one sliced pair
+//   BatchGEMMSeq::operator()     src/core/batch_gemm.hpp:1563-1684   replays the plan: v += scale * H c
+//   IterativeMatrixFunctions::davidson          src/core/iterative_matrix_functions.hpp:864-1173
+//   IterativeMatrixFunctions::olsen_precondition                     :93-108
+//   EffectiveHamiltonian::{precompute, operator(), eigs, post_precompute}
+//                                src/dmrg/effective_hamiltonian.hpp:224-251, 449-467, 470-558
+//
+// Everything numerical happens on the device through include/b2x.h; a non-zero return becomes
+// std::runtime_error (the reference throws at this boundary).  Header-only, like the reference.
+#pragma once
+#include "../../../include/b2x.h"
+#include <algorithm>
+#include <cassert>
+#include <chrono>
+#include <cstdio>
+#include <cmath>
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+namespace b2xh {
+
+inline void check(int rc) {
+    if (rc != 0)
+        throw std::runtime_error(std::string("b2x: ") + b2x_last_error());
+}
+
+struct GMatrix {
+    double *data;
+    int m, n;
+    GMatrix(double *data, int m, int n) : data(data), m(m), n(n) {}
+    size_t size() const { return (size_t)m * n; }
+    GMatrix flip_dims() const { return GMatrix(data, n, m); }
+    GMatrix shift_ptr(size_t l) const { return GMatrix(data + l, m, n); }
+    double &operator()(int i, int j) const { return data[(size_t)i * n + j]; }
+};
+
+enum struct SeqTypes : uint8_t { None = 0, Simple = 1, Auto = 2, Tasked = 4, SimpleTasked = 5, Device = 8 };
+
+// Plan recorder + device executor.  As in the reference, psi / psi' operands are recorded as OFFSETS
+// ("pointers from null": precompute() sets cmat->data = vmat->data = 0), operator operands as absolute
+// host pointers; the operator ranges are uploaded once, when the plan is first executed.
+struct BatchGEMMSeq {
+    SeqTypes mode = SeqTypes::Device;
+    std::vector<b2x_pair> pairs;
+    std::vector<const double *> y_ptr, z_ptr; // absolute operator pointers of stage 0 / stage 1
+    size_t max_work = 0;
+    size_t nflop = 0, cumulative_nflop = 0;
+    b2x_arena *arena = nullptr;
+    b2x_plan *plan = nullptr;
+    size_t psi_len = 0, sigma_len = 0;
+    BatchGEMMSeq(size_t /*max_batch_flops*/ = 1LL << 24, SeqTypes mode = SeqTypes::Device) : mode(mode) {}
+    ~BatchGEMMSeq() { deallocate(); }
+    BatchGEMMSeq(const BatchGEMMSeq &) = delete;
+    BatchGEMMSeq &operator=(const BatchGEMMSeq &) = delete;
+
+    void push(int ta0, int tb0, int m0, int n0, int k0, double alpha0, const double *a0, int lda0, const double *b0,
+              int ldb0, int ta1, int m1, int k1, double alpha1, const double *a1, int lda1, double *c1, int ldc1) {
+        if (plan != nullptr)
+            throw std::runtime_error("BatchGEMMSeq: plan already uploaded; call clear() first");
+        b2x_pair p{};
+        p.m0 = m0, p.n0 = n0, p.k0 = k0, p.lda0 = lda0, p.ldb0 = ldb0;
+        p.m1 = m1, p.n1 = n0, p.k1 = k1, p.lda1 = lda1, p.ldc1 = ldc1;
+        p.ta0 = (uint8_t)ta0, p.tb0 = (uint8_t)tb0, p.ta1 = (uint8_t)ta1, p.tb1 = 0;
+        p.alpha0 = alpha0, p.alpha1 = alpha1;
+        p.x_off = (uint64_t)(a0 - (const double *)0);
+        p.v_off = (uint64_t)(c1 - (double *)0);
+        pairs.push_back(p);
+        y_ptr.push_back(b0), z_ptr.push_back(a1);
+        max_work = std::max(max_work, (size_t)m0 * n0);
+        nflop += (size_t)m0 * n0 * k0 + (size_t)m1 * n0 * k1;
+    }
+    // [c] += scale * op(bra) x [a] x op(ket)      conj & 1 == transpose (real double)
+    void rotate(const GMatrix &a, const GMatrix &c, const GMatrix &bra, uint8_t conj_bra, const GMatrix &ket,
+                uint8_t conj_ket, double scale) {
+        const int tb0 = conj_ket & 1, ta1 = conj_bra & 1;
+        const int wn = tb0 ? ket.m : ket.n, k0 = tb0 ? ket.n : ket.m;
+        push(0, tb0, a.m, wn, k0, 1.0, a.data, a.n, ket.data, ket.n, ta1, c.m, a.m, scale, bra.data, bra.n, c.data,
+             c.n);
+    }
+    //  dleft: [c] = scale * [bra] (= [da] x [db]) * [a] * [ket]
+    // !dleft: [c] = scale * [bra] * [a] * [ket] (= [da] x [db])     one of da / db is 1 x 1
+    void three_rotate(const GMatrix &a, const GMatrix &c, const GMatrix &bra, bool conj_bra, const GMatrix &ket,
+                      bool conj_ket, const GMatrix &da, bool dconja, const GMatrix &db, bool dconjb, bool dleft,
+                      double scale, uint64_t stride) {
+        const bool a_scalar = da.m == 1 && da.n == 1, b_scalar = db.m == 1 && db.n == 1;
+        if (!a_scalar && !b_scalar)
+            throw std::runtime_error("three_rotate: one factor of the delayed operator must be 1 x 1");
+        if (dleft) {
+            dconja ^= conj_bra, dconjb ^= conj_bra;
+            int am = (dconja ? da.m : da.n) * (dconjb ? db.m : db.n);
+            int cm = (dconja ? da.n : da.m) * (dconjb ? db.n : db.m);
+            uint32_t ast = (uint32_t)(conj_bra ? stride / bra.n : stride % bra.n);
+            uint32_t cst = (uint32_t)(conj_bra ? stride % bra.n : stride / bra.n);
+            const int tb0 = conj_ket ? 1 : 0;
+            const int wn = conj_ket ? ket.m : ket.n, k0 = conj_ket ? ket.n : ket.m;
+            const GMatrix &big = a_scalar ? db : da;
+            const bool bconj = a_scalar ? dconjb : dconja;
+            const double sc = a_scalar ? *da.data : *db.data;
+            push(0, tb0, am, wn, k0, scale, a.data + (size_t)ast * a.n, a.n, ket.data, ket.n, bconj ? 1 : 0, cm, am, sc,
+                 big.data, big.n, c.data + (size_t)cst * c.n, c.n);
+        } else {
+            dconja ^= conj_ket, dconjb ^= conj_ket;
+            int kn = (dconja ? da.m : da.n) * (dconjb ? db.m : db.n);
+            int km = (dconja ? da.n : da.m) * (dconjb ? db.n : db.m);
+            uint32_t ast = (uint32_t)(conj_ket ? stride % ket.n : stride / ket.n);
+            uint32_t cst = (uint32_t)(conj_ket ? stride / ket.n : stride % ket.n);
+            const GMatrix &big = a_scalar ? db : da;
+            const bool bconj = a_scalar ? dconjb : dconja;
+            const double sc = a_scalar ? *da.data : *db.data;
+            // work = a[:, ast:ast+km] * op(big): conj flag 1 = transpose, 2 = plain (batch_gemm.hpp:989-1003)
+            push(0, bconj ? 1 : 0, a.m, kn, km, sc, a.data + ast, a.n, big.data, big.n, conj_bra ? 1 : 0, c.m, a.m,
+                 scale, bra.data, bra.n, c.data + cst, c.n);
+        }
+    }
+    // upload the operator ranges + compile the device plan (lazily, on first execution)
+    void prepare(size_t psi_len_, size_t sigma_len_) {
+        if (plan != nullptr)
+            return;
+        psi_len = psi_len_, sigma_len = sigma_len_;
+        std::vector<std::pair<const double *, size_t>> ext;
+        for (size_t i = 0; i < pairs.size(); i++) {
+            const b2x_pair &p = pairs[i];
+            size_t ey = p.tb0 ? (size_t)(p.n0 - 1) * p.ldb0 + p.k0 : (size_t)(p.k0 - 1) * p.ldb0 + p.n0;
+            size_t ez = p.ta1 ? (size_t)(p.k1 - 1) * p.lda1 + p.m1 : (size_t)(p.m1 - 1) * p.lda1 + p.k1;
+            ext.emplace_back(y_ptr[i], ey), ext.emplace_back(z_ptr[i], ez);
+        }
+        std::sort(ext.begin(), ext.end());
+        std::vector<const double *> bases;
+        std::vector<size_t> lens;
+        for (auto &e : ext) {
+            if (!bases.empty() && e.first <= bases.back() + lens.back())
+                lens.back() = std::max(lens.back(), (size_t)(e.first - bases.back()) + e.second);
+            else
+                bases.push_back(e.first), lens.push_back(e.second);
+        }
+        check(b2x_arena_create(&arena, bases.size(), bases.data(), lens.data()));
+        for (size_t i = 0; i < pairs.size(); i++) {
+            check(b2x_arena_resolve(arena, y_ptr[i], &pairs[i].y_off));
+            check(b2x_arena_resolve(arena, z_ptr[i], &pairs[i].z_off));
+        }
+        check(b2x_plan_create(&plan, arena, pairs.size(), pairs.data(), psi_len, sigma_len, nullptr));
+    }
+    // Matrix multiply vector (c) => vector (v):  v += scale * H c   (host pointers)
+    void operator()(const GMatrix &c, const GMatrix &v, double scale = 1.0) {
+        if (pairs.empty())
+            return;
+        prepare(c.size(), v.size());
+        if (c.size() != psi_len || v.size() != sigma_len)
+            throw std::runtime_error("BatchGEMMSeq::operator(): vector length differs from the recorded plan");
+        check(b2x_plan_execute(plan, c.data, v.data, scale, 0, nullptr));
+        cumulative_nflop += nflop;
+    }
+    // same with device-resident vectors (what Davidson uses)
+    void apply_device(const double *c_dev, double *v_dev, double scale, void *stream = nullptr) {
+        if (plan == nullptr)
+            throw std::runtime_error("BatchGEMMSeq::apply_device: call prepare() first");
+        check(b2x_plan_execute(plan, c_dev, v_dev, scale, 1, stream));
+        cumulative_nflop += nflop;
+    }
+    void deallocate() {
+        if (plan)
+            b2x_plan_destroy(plan), plan = nullptr;
+        if (arena)
+            b2x_arena_destroy(arena), arena = nullptr;
+    }
+    void clear() {
+        deallocate();
+        pairs.clear(), y_ptr.clear(), z_ptr.clear();
+        max_work = 0, nflop = 0;
+    }
+};
+
+// device buffer (RAII)
+struct DeviceVector {
+    double *p = nullptr;
+    size_t n = 0;
+    explicit DeviceVector(size_t n) : n(n) { check(b2x_device_alloc((void **)&p, std::max<size_t>(n, 1) * 8)); }
+    ~DeviceVector() {
+        if (p)
+            b2x_device_free(p);
+    }
+    DeviceVector(const DeviceVector &) = delete;
+    void upload(const double *h) { check(b2x_memcpy_h2d(p, h, n * 8)); }
+    void download(double *h) const { check(b2x_memcpy_d2h(h, p, n * 8)); }
+};
+
+// symmetric eigenproblem of the (<= 50 x 50) subspace matrix: cyclic Jacobi, eigenvalues ascending,
+// row j of `a` = eigenvector j on return (the layout davidson uses: sigma_j' = sum_i alpha(j,i) sigma_i)
+inline void small_eigs(std::vector<double> &a, std::vector<double> &w, int m) {
+    std::vector<double> v((size_t)m * m, 0.0);
+    for (int i = 0; i < m; i++)
+        v[(size_t)i * m + i] = 1.0;
+    for (int i = 0; i < m; i++)
+        for (int j = i + 1; j < m; j++)
+            a[(size_t)i * m + j] = a[(size_t)j * m + i]; // lower triangle was filled
+    for (int sweep = 0; sweep < 100; sweep++) {
+        double off = 0;
+        for (int i = 0; i < m; i++)
+            for (int j = 0; j < i; j++)
+                off += a[(size_t)i * m + j] * a[(size_t)i * m + j];
+        if (off < 1e-300)
+            break;
+        for (int p = 0; p < m; p++)
+            for (int q = p + 1; q < m; q++) {
+                double apq = a[(size_t)p * m + q];
+                if (std::fabs(apq) < 1e-300)
+                    continue;
+                double theta = (a[(size_t)q * m + q] - a[(size_t)p * m + p]) / (2.0 * apq);
+                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < m; k++) {
+                    double akp = a[(size_t)k * m + p], akq = a[(size_t)k * m + q];
+                    a[(size_t)k * m + p] = cs * akp - sn * akq, a[(size_t)k * m + q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < m; k++) {
+                    double apk = a[(size_t)p * m + k], aqk = a[(size_t)q * m + k];
+                    a[(size_t)p * m + k] = cs * apk - sn * aqk, a[(size_t)q * m + k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < m; k++) {
+                    double vkp = v[(size_t)k * m + p], vkq = v[(size_t)k * m + q];
+                    v[(size_t)k * m + p] = cs * vkp - sn * vkq, v[(size_t)k * m + q] = sn * vkp + cs * vkq;
+                }
+            }
+    }
+    std::vector<int> idx(m);
+    for (int i = 0; i < m; i++)
+        idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int x, int y) { return a[(size_t)x * m + x] < a[(size_t)y * m + y]; });
+    w.resize(m);
+    std::vector<double> out((size_t)m * m);
+    for (int j = 0; j < m; j++) {
+        w[j] = a[(size_t)idx[j] * m + idx[j]];
+        for (int i = 0; i < m; i++)
+            out[(size_t)j * m + i] = v[(size_t)i * m + idx[j]];
+    }
+    a.swap(out);
+}
+
+struct IterativeMatrixFunctions {
+    // Davidson for the k lowest eigenpairs, every psi-sized vector resident on the device.
+    //   op(b_dev, sigma_dev): sigma += H b   (sigma arrives zeroed, as in the reference :972-973)
+    //   aa_dev: diagonal of H (Olsen preconditioner), vs_dev: k initial guesses, overwritten with eigenvectors.
+    // Same control flow as the reference (:864-1173): orthonormalise guesses, expand by one preconditioned
+    // residual per iteration, full Rayleigh-Ritz rotation of (b, sigma) each iteration, converge on
+    // |r|^2 < conv_thrd, collapse to deflation_min_size vectors at deflation_max_size.
+    static std::vector<double> davidson(const std::function<void(const double *, double *)> &op, const double *aa_dev,
+                                        std::vector<double *> &vs_dev, size_t n, int &ndav, double conv_thrd = 5E-6,
+                                        int max_iter = 5000, int soft_max_iter = -1, int deflation_min_size = 2,
+                                        int deflation_max_size = 50, bool iprint = false) {
+        const int k = (int)vs_dev.size();
+        if (deflation_min_size < k)
+            deflation_min_size = k;
+        if (deflation_max_size < k + k / 2)
+            deflation_max_size = k + k / 2;
+        if (deflation_max_size > 63)
+            deflation_max_size = 63;
+        const int M = deflation_max_size;
+        std::vector<std::unique_ptr<DeviceVector>> store;
+        auto mk = [&]() {
+            store.emplace_back(new DeviceVector(n));
+            return store.back()->p;
+        };
+        std::vector<double *> bs(M), sg(M), tb(M), ts(M);
+        for (int i = 0; i < M; i++)
+            bs[i] = mk(), sg[i] = mk(), tb[i] = mk(), ts[i] = mk();
+        double *q = mk(), *t = mk();
+        auto dot = [&](const double *x, const double *y) {
+            double r;
+            check(b2x_vec_dot(x, y, n, &r, nullptr));
+            return r;
+        };
+        for (int i = 0; i < k; i++)
+            check(b2x_vec_copy(vs_dev[i], bs[i], n, nullptr));
+        int m = k;
+        for (int i = 0; i < k; i++) {
+            for (int j = 0; j < i; j++)
+                check(b2x_vec_axpy(-dot(bs[j], bs[i]), bs[j], bs[i], n, nullptr));
+            double nrm = std::sqrt(dot(bs[i], bs[i]));
+            if (nrm * nrm < 1E-14 && i > 0) {
+                m = i;
+                break;
+            }
+            if (nrm * nrm < 1E-14)
+                throw std::runtime_error("Cannot generate initial guess 0 for Davidson (zero norm)!");
+            check(b2x_vec_scal(1.0 / nrm, bs[i], n, nullptr));
+        }
+        std::vector<double> eigvals(k), ld;
+        int ck = 0, msig = 0, xiter = 0;
+        double qq = 0;
+        while (xiter < max_iter && (soft_max_iter == -1 || xiter < soft_max_iter)) {
+            xiter++;
+            for (int i = msig; i < m; i++, msig++) {
+                check(b2x_vec_zero(sg[i], n, nullptr));
+                op(bs[i], sg[i]);
+            }
+            // Rayleigh-Ritz in the current basis
+            std::vector<double> alpha((size_t)m * m, 0.0), row(m);
+            for (int j = 0; j < m; j++) { // alpha(i, j) = <b_i, sigma_j>, i >= j
+                std::vector<const double *> ptrs(bs.begin() + j, bs.begin() + m);
+                check(b2x_vec_multi_dot(ptrs.data(), m - j, sg[j], n, row.data(), nullptr));
+                for (int i = j; i < m; i++)
+                    alpha[(size_t)i * m + j] = row[i - j];
+            }
+            small_eigs(alpha, ld, m);
+            // sigma[:] = alpha sigma[:],  b[:] = alpha b[:]   (full rotation, as the reference does)
+            {
+                std::vector<const double *> ps(sg.begin(), sg.begin() + m), pb(bs.begin(), bs.begin() + m);
+                for (int j = 0; j < m; j++) {
+                    check(b2x_vec_lincomb(ps.data(), m, &alpha[(size_t)j * m], ts[j], n, nullptr));
+                    check(b2x_vec_lincomb(pb.data(), m, &alpha[(size_t)j * m], tb[j], n, nullptr));
+                }
+                for (int j = 0; j < m; j++)
+                    std::swap(sg[j], ts[j]), std::swap(bs[j], tb[j]);
+            }
+            for (int i = 0; i < ck; i++) { // re-check the roots already counted as converged
+                check(b2x_vec_copy(sg[i], q, n, nullptr));
+                check(b2x_vec_axpy(-ld[i], bs[i], q, n, nullptr));
+                if (std::fabs(dot(q, q)) >= conv_thrd) {
+                    ck = i;
+                    break;
+                }
+            }
+            check(b2x_vec_copy(sg[ck], q, n, nullptr));
+            check(b2x_vec_axpy(-ld[ck], bs[ck], q, n, nullptr));
+            qq = dot(q, q);
+            if (iprint)
+                printf("%6d%6d%6d%15.8f%13.2e\n", xiter, m, ck, ld[ck], std::fabs(qq));
+            // olsen_precondition(q, bs[ck], ld[ck], aa)
+            check(b2x_vec_olsen_prepare(q, t, bs[ck], aa_dev, ld[ck], n, nullptr));
+            {
+                double cq = dot(bs[ck], q), ct = dot(bs[ck], t);
+                check(b2x_vec_axpy(-cq / ct, t, q, n, nullptr));
+            }
+            eigvals.resize(ck + 1);
+            for (int i = 0; i <= ck; i++)
+                eigvals[i] = ld[i];
+            if (std::fabs(qq) < conv_thrd && m >= k) {
+                ck++;
+                if (ck == k)
+                    break;
+            } else {
+                if (m >= deflation_max_size)
+                    m = msig = deflation_min_size;
+                for (int j = 0; j < m; j++)
+                    check(b2x_vec_axpy(-dot(bs[j], q), bs[j], q, n, nullptr));
+                check(b2x_vec_scal(1.0 / std::sqrt(dot(q, q)), q, n, nullptr));
+                check(b2x_vec_copy(q, bs[m], n, nullptr));
+                m++;
+            }
+            if (xiter == soft_max_iter)
+                break;
+        }
+        if (xiter == soft_max_iter)
+            eigvals.resize(k, 0);
+        if (xiter == max_iter)
+            throw std::runtime_error("Davidson: only " + std::to_string(ck) + " converged!");
+        for (int i = 0; i < k; i++)
+            check(b2x_vec_copy(bs[i], vs_dev[i], n, nullptr));
+        check(b2x_device_sync());
+        ndav = xiter;
+        return eigvals;
+    }
+};
+
+// The local problem of one site at the level this path sees it: a recorded plan (what precompute() builds),
+// the diagonal and the wavefunction.  eigs() == EffectiveHamiltonian::eigs (effective_hamiltonian.hpp:470-558):
+// returns (energy, ndav, nflop, tdav); ket is overwritten with the eigenvector.
+struct EffectiveHamiltonian {
+    std::shared_ptr<BatchGEMMSeq> seq;
+    std::vector<double> diag;
+    size_t n;
+    EffectiveHamiltonian(const std::shared_ptr<BatchGEMMSeq> &seq, const std::vector<double> &diag)
+        : seq(seq), diag(diag), n(diag.size()) {}
+    void precompute() { seq->prepare(n, n); }
+    void post_precompute() { seq->deallocate(); }
+    // [c] += factor * [H_eff] x [b]    (host vectors)
+    void operator()(const GMatrix &b, const GMatrix &c, double factor = 1.0) {
+        precompute();
+        (*seq)(b, c, factor);
+    }
+    std::tuple<double, int, size_t, double> eigs(std::vector<double> &ket, double conv_thrd = 5E-6, int max_iter = 5000,
+                                                 int soft_max_iter = -1, int deflation_min_size = 2,
+                                                 int deflation_max_size = 50, bool iprint = false) {
+        if (ket.size() != n)
+            throw std::runtime_error("EffectiveHamiltonian::eigs: ket length differs from diag");
+        precompute();
+        seq->cumulative_nflop = 0;
+        DeviceVector dk(n), dd(n);
+        dk.upload(ket.data()), dd.upload(diag.data());
+        std::vector<double *> vs{dk.p};
+        int ndav = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        auto f = [this](const double *b, double *s) { seq->apply_device(b, s, 1.0); };
+        std::vector<double> eners = IterativeMatrixFunctions::davidson(f, dd.p, vs, n, ndav, conv_thrd, max_iter,
+                                                                       soft_max_iter, deflation_min_size,
+                                                                       deflation_max_size, iprint);
+        double tdav = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        dk.download(ket.data());
+        size_t nf = seq->cumulative_nflop;
+        seq->cumulative_nflop = 0;
+        return std::make_tuple(eners[0], ndav, nf, tdav);
+    }
+};
+
+} // namespace b2xh

@@ -1,0 +1,116 @@
+// b2x_host_py.cpp — pybind11 surface of the C++ host mirror (module `b2x_host`), the analogue of block2's
+// bindings for these classes: BatchGEMMSeq (src/pybind/pybind_core.hpp:3793-3830), EffectiveHamiltonian
+// incl. __call__ / eigs (src/pybind/pybind_dmrg.hpp:588-640), SeqTypes (pybind_core.hpp:2063-2071).
+// GMatrix arguments are numpy arrays (operators: 2-D float64, C-contiguous) or integer element offsets
+// (psi / psi' operands, which block2 records "from null").
+#include "b2x_host.hpp"
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+namespace py = pybind11;
+using namespace b2xh;
+typedef py::array_t<double, py::array::c_style | py::array::forcecast> arr;
+
+static GMatrix gm(const arr &a) {
+    if (a.ndim() != 2)
+        throw std::runtime_error("expected a 2-D float64 array");
+    return GMatrix(const_cast<double *>(a.data()), (int)a.shape(0), (int)a.shape(1));
+}
+static GMatrix off(uint64_t o, int m, int n) { return GMatrix((double *)0 + o, m, n); }
+
+struct PySeq : BatchGEMMSeq {
+    std::vector<py::object> keep; // operator arrays must outlive the plan upload
+    using BatchGEMMSeq::BatchGEMMSeq;
+};
+
+PYBIND11_MODULE(b2x_host, m) {
+    m.doc() = "C++ host mirror of block2's H.psi interface over the MI355X C ABI (include/b2x.h)";
+    py::enum_<SeqTypes>(m, "SeqTypes", py::arithmetic())
+        .value("Nothing", SeqTypes::None)
+        .value("Simple", SeqTypes::Simple)
+        .value("Auto", SeqTypes::Auto)
+        .value("Tasked", SeqTypes::Tasked)
+        .value("SimpleTasked", SeqTypes::SimpleTasked)
+        .value("Device", SeqTypes::Device);
+    py::class_<PySeq, std::shared_ptr<PySeq>>(m, "BatchGEMMSeq")
+        .def(py::init([](size_t max_batch_flops, SeqTypes mode) { return std::make_shared<PySeq>(max_batch_flops, mode); }),
+             py::arg("max_batch_flops") = (size_t)1 << 24, py::arg("mode") = SeqTypes::Device)
+        .def_readwrite("mode", &PySeq::mode)
+        .def_readonly("max_work", &PySeq::max_work)
+        .def_readonly("nflop", &PySeq::nflop)
+        .def_readwrite("cumulative_nflop", &PySeq::cumulative_nflop)
+        .def_property_readonly("n_pairs", [](const PySeq &s) { return s.pairs.size(); })
+        // rotate(a=(offset, m, n), c=(offset, m, n), bra, conj_bra, ket, conj_ket, scale)
+        .def("rotate",
+             [](PySeq &s, std::tuple<uint64_t, int, int> a, std::tuple<uint64_t, int, int> c, arr bra, uint8_t conj_bra,
+                arr ket, uint8_t conj_ket, double scale) {
+                 s.keep.push_back(bra), s.keep.push_back(ket);
+                 s.rotate(off(std::get<0>(a), std::get<1>(a), std::get<2>(a)),
+                          off(std::get<0>(c), std::get<1>(c), std::get<2>(c)), gm(bra), conj_bra, gm(ket), conj_ket,
+                          scale);
+             })
+        .def("three_rotate",
+             [](PySeq &s, std::tuple<uint64_t, int, int> a, std::tuple<uint64_t, int, int> c, arr bra, bool conj_bra,
+                arr ket, bool conj_ket, arr da, bool dconja, arr db, bool dconjb, bool dleft, double scale,
+                uint64_t stride) {
+                 s.keep.push_back(bra), s.keep.push_back(ket), s.keep.push_back(da), s.keep.push_back(db);
+                 s.three_rotate(off(std::get<0>(a), std::get<1>(a), std::get<2>(a)),
+                                off(std::get<0>(c), std::get<1>(c), std::get<2>(c)), gm(bra), conj_bra, gm(ket),
+                                conj_ket, gm(da), dconja, gm(db), dconjb, dleft, scale, stride);
+             })
+        // load a recorded plan: b2x_pair records (structured array viewed as bytes) + the operator arena
+        .def("load_pairs",
+             [](PySeq &s, py::array pairs, arr arena) {
+                 if (pairs.itemsize() != (py::ssize_t)sizeof(b2x_pair))
+                     throw std::runtime_error("pairs: itemsize must equal sizeof(b2x_pair)");
+                 s.keep.push_back(arena);
+                 const b2x_pair *p = (const b2x_pair *)pairs.data();
+                 for (py::ssize_t i = 0; i < pairs.shape(0); i++) {
+                     const b2x_pair &q = p[i];
+                     s.push(q.ta0, q.tb0, q.m0, q.n0, q.k0, q.alpha0, (const double *)0 + q.x_off, q.lda0,
+                            arena.data() + q.y_off, q.ldb0, q.ta1, q.m1, q.k1, q.alpha1, arena.data() + q.z_off, q.lda1,
+                            (double *)0 + q.v_off, q.ldc1);
+                 }
+             })
+        .def("__call__",
+             [](PySeq &s, py::array_t<double, py::array::c_style> c, py::array_t<double, py::array::c_style> v,
+                double scale) {
+                 s(GMatrix(c.mutable_data(), (int)c.size(), 1), GMatrix(v.mutable_data(), (int)v.size(), 1), scale);
+             },
+             py::arg("c"), py::arg("v"), py::arg("scale") = 1.0)
+        .def("deallocate", &PySeq::deallocate)
+        .def("clear", [](PySeq &s) {
+            s.clear();
+            s.keep.clear();
+        });
+    py::class_<EffectiveHamiltonian>(m, "EffectiveHamiltonian")
+        .def(py::init([](std::shared_ptr<PySeq> seq, std::vector<double> diag) {
+            return new EffectiveHamiltonian(std::static_pointer_cast<BatchGEMMSeq>(seq), diag);
+        }))
+        .def("precompute", &EffectiveHamiltonian::precompute)
+        .def("post_precompute", &EffectiveHamiltonian::post_precompute)
+        .def("__call__",
+             [](EffectiveHamiltonian &h, py::array_t<double, py::array::c_style> b,
+                py::array_t<double, py::array::c_style> c, double factor) {
+                 h(GMatrix(b.mutable_data(), (int)b.size(), 1), GMatrix(c.mutable_data(), (int)c.size(), 1), factor);
+             },
+             py::arg("b"), py::arg("c"), py::arg("factor") = 1.0)
+        // eigs(ket, conv_thrd, max_iter, soft_max_iter, deflation_min_size, deflation_max_size, iprint)
+        //   -> (energy, ndav, nflop, tdav, ket_out)
+        .def("eigs",
+             [](EffectiveHamiltonian &h, std::vector<double> ket, double conv_thrd, int max_iter, int soft_max_iter,
+                int deflation_min_size, int deflation_max_size, bool iprint) {
+                 auto r = h.eigs(ket, conv_thrd, max_iter, soft_max_iter, deflation_min_size, deflation_max_size, iprint);
+                 return py::make_tuple(std::get<0>(r), std::get<1>(r), std::get<2>(r), std::get<3>(r),
+                                       py::array_t<double>(ket.size(), ket.data()));
+             },
+             py::arg("ket"), py::arg("conv_thrd") = 5E-6, py::arg("max_iter") = 5000, py::arg("soft_max_iter") = -1,
+             py::arg("deflation_min_size") = 2, py::arg("deflation_max_size") = 50, py::arg("iprint") = false);
+    m.def("device_init", [](int ordinal) { check(b2x_device_init(ordinal)); }, py::arg("ordinal") = 0);
+    m.def("small_eigs", [](std::vector<double> a, int n) {
+        std::vector<double> w;
+        small_eigs(a, w, n);
+        return py::make_tuple(w, a);
+    });
+}

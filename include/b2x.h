@@ -139,6 +139,11 @@ int b2x_vec_zero(double *x, size_t n, void *stream);
 /* Olsen/diagonal preconditioner step of davidson (iterative_matrix_functions.hpp:1084-1087):
  * q[i] /= (diag[i] - shift) when |diag[i]-shift| > 1e-12 */
 int b2x_vec_precondition(double *q, const double *diag, double shift, size_t n, void *stream);
+/* first half of olsen_precondition (iterative_matrix_functions.hpp:93-108): t = c; then, where
+ * |ld - diag[i]| > 1e-12:  t[i] /= ld - diag[i],  q[i] /= ld - diag[i].  (The caller finishes with
+ * q += -(c.q)/(c.t) * t using b2x_vec_multi_dot + b2x_vec_axpy.) */
+int b2x_vec_olsen_prepare(double *q, double *t, const double *c, const double *diag, double ld, size_t n,
+                          void *stream);
 /* gram[j] = <vs[j], x> for j < nv; vs = nv device pointers (host array of device pointers) */
 int b2x_vec_multi_dot(const double *const *vs, int nv, const double *x, size_t n, double *host_result,
                       void *stream);
