@@ -166,7 +166,7 @@ int b2x_arena_create(b2x_arena **out, size_t n_ranges, const double *const *host
         tot += lens[i];
     }
     a->len = tot, a->owned = true;
-    hipError_t e = hipMalloc((void **)&a->dev, (tot ? tot : 1) * sizeof(double));
+    hipError_t e = hipMalloc((void **)&a->dev, (tot + 8) * sizeof(double)); // +64 B: 16-byte DMA granules may straddle the end
     if (e != hipSuccess) {
         delete a;
         return fail(B2X_ERR_NOMEM, std::string("hipMalloc(arena): ") + hipGetErrorString(e));
@@ -269,7 +269,7 @@ int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, cons
             rc = upload(&p->d_gtiles, cp.gtiles);
         p->steps = cp.steps;
         if (rc == B2X_OK && cp.scratch_elems) {
-            hipError_t e = hipMalloc((void **)&p->d_scratch, cp.scratch_elems * sizeof(double));
+            hipError_t e = hipMalloc((void **)&p->d_scratch, (cp.scratch_elems + 8) * sizeof(double));
             if (e != hipSuccess)
                 rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(W scratch): ") + hipGetErrorString(e));
         }
@@ -315,7 +315,7 @@ int b2x_plan_execute(b2x_plan *p, const double *psi, double *sigma, double scale
     if (on_device)
         return run_plan(p, psi, sigma, scale, st);
     if (!p->d_psi)
-        HIPCHK(hipMalloc((void **)&p->d_psi, (p->psi_len ? p->psi_len : 1) * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&p->d_psi, (p->psi_len + 8) * sizeof(double)));
     if (!p->d_sigma)
         HIPCHK(hipMalloc((void **)&p->d_sigma, (p->sigma_len ? p->sigma_len : 1) * sizeof(double)));
     HIPCHK(hipMemcpyAsync(p->d_psi, psi, p->psi_len * sizeof(double), hipMemcpyHostToDevice, st));

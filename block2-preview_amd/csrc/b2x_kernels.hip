@@ -151,25 +151,28 @@ __global__ __launch_bounds__(NW * 64) void hpsi_main(const DPart *__restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
-// gg_kernel<TMF, CF>: grouped GEMM of the two-stage path (large sectors).  One workgroup of 4 waves
-// (one per SIMD, up to 512 VGPRs each) owns a (TMF*16) x (4*CF*16) output tile and walks a list of
-// K-segments   C[window] += A(mr x K) * B(K x nc).
+// gg_kernel<TMF, CF, NW>: grouped GEMM of the two-stage path (large sectors).  One workgroup of NW waves
+// (two per SIMD) owns a (TMF*16) x (NW*CF*16) output tile and walks a list of K-segments
+//     C[window] += A(mr x K) * B(K x nc).
 //   stage 0 items: one segment, A = X (psi), B = op(Y) (arena), tile stored (x alpha) into the W scratch
 //   stage 1 items: many segments, A = op(Z) (arena), B = W (scratch), tile stored into a partial slab
-// Wave w owns CF column fragments x all TMF row fragments (acc = TMF*CF*8 VGPRs).  A chunks (16 k)
-// are staged global -> registers -> LDS one chunk ahead (double-buffered LDS, one barrier per chunk);
-// B fragments are private to a wave and are prefetched one chunk ahead straight into registers.
+// Wave w owns CF column fragments x all TMF row fragments (acc = TMF*CF*8 VGPRs, in VGPRs: no AGPR traffic).
+// A chunks (TM x 16 k) go HBM/L2 -> LDS by LDS-DMA (global_load_lds, 16 B per lane, no staging registers,
+// no ds_write), double-buffered, one barrier per chunk; the DMA destination is lane-linear, so the bank
+// swizzle is applied on the per-lane SOURCE address and again on the ds_read address.  B fragments are
+// private to a wave and are prefetched one chunk ahead straight into registers.  Row tiles are cut at the
+// row-slice boundaries of the sector, so a segment's rows always cover its tile: only columns (B side)
+// and the k tail need masking, and both are applied to the B registers.
 template <int TMF, int CF, int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
-                                                     const double *__restrict__ arena,
-                                                     const double *__restrict__ psi, double *__restrict__ scratch,
-                                                     double *__restrict__ slabs) {
-    constexpr int TM = TMF * 16, LDX = 18;
-    constexpr int LDZT = (TM % 32 == 0) ? TM + 16 : TM;
-    constexpr int ABUF = (TM * LDX > 16 * LDZT) ? TM * LDX : 16 * LDZT;
-    constexpr int NT = NW * 64;
-    constexpr int NA = TM * 16 / NT; // A elements staged per thread per chunk
-    __shared__ double lds[2 * ABUF];
+__global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
+                                                         const double *__restrict__ arena,
+                                                         const double *__restrict__ psi, double *__restrict__ scratch,
+                                                         double *__restrict__ slabs) {
+    constexpr int TM = TMF * 16, NT = NW * 64;
+    constexpr int ABUF = TM * 16;        // doubles per LDS buffer (unpadded: the DMA image is lane-linear)
+    constexpr int NG = TM * 8;           // 16-byte granules per chunk
+    constexpr int NI = (NG + NT - 1) / NT; // DMA instructions per thread per chunk
+    __shared__ __attribute__((aligned(16))) double lds[2 * ABUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -182,110 +185,163 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void gg_kernel(const GSeg *__restr
         for (int q = 0; q < CF; q++)
             acc[f][q] = v4d{0.0, 0.0, 0.0, 0.0};
 
-    double areg[NA];
     double bnxt[CF][4], bcur[CF][4];
-    uint32_t amask = 0, bmask = 0; // validity bits of the chunk in flight (applied when it is committed)
-
-    // Issue the global loads of one 16-k chunk of segment S at k offset kb.  Loads are unconditional, from
-    // clamped (always valid) addresses; validity is recorded as bit masks and applied in commit().  A
-    // branch or a select next to the load makes hipcc wait for the data right here (vmcnt(0) per element),
-    // which would serialize the chunk instead of overlapping it with the MFMAs of the current chunk.
-    auto fetch = [&](const GSeg &S, int kb) {
-        const double *A = (S.a_src == 0 ? arena : (S.a_src == 1 ? psi : scratch)) + S.a_off;
-        const double *B = (S.b_src == 0 ? arena : (S.b_src == 1 ? psi : scratch)) + S.b_off;
-        const bool kmaj = (S.a_sk != 1); // A stored with the row index contiguous
-        amask = 0, bmask = 0;
+    // ---- per-segment state: 32-bit element offsets from wave-uniform bases --------------------------
+    const double *sA = arena, *sB = arena;
+    uint32_t aoff[NI];   // per DMA instruction: row part of the source offset
+    uint32_t akq[NI];    // per DMA instruction: k (rowmaj: first k of the granule; kmaj: k of the granule)
+    uint32_t boff[CF];   // clamped column * b_sc
+    uint32_t colmask = 0, akmax = 0, bkmax = 0, astep = 1;
+    bool s_kmaj = false, cols_full = false;
 #pragma unroll
-        for (int i = 0; i < NA; i++) {
-            int e = tid + NT * i;
-            int row = kmaj ? (e % TM) : (e >> 4);
-            int kk = kmaj ? (e / TM) : (e & 15);
-            int rr = row - S.tr0;
-            amask |= (uint32_t)(rr >= 0 && rr < S.mr && kb + kk < S.K) << i;
-            int rc_ = min(max(rr, 0), S.mr - 1), kc_ = min(kb + kk, S.K - 1);
-            areg[i] = A[(int64_t)rc_ * S.a_sr + (int64_t)kc_ * S.a_sk];
+    for (int j = 0; j < NI; j++)
+        aoff[j] = 0, akq[j] = 0;
+
+    auto enter = [&, arena, psi, scratch](const GSeg &S) __attribute__((always_inline)) {
+        sA = (S.a_src == 0 ? arena : (S.a_src == 1 ? psi : scratch)) + S.a_off;
+        sB = (S.b_src == 0 ? arena : (S.b_src == 1 ? psi : scratch)) + S.b_off;
+        s_kmaj = (S.a_sk != 1);
+        cols_full = (S.tc0 == 0 && S.nc >= item.cols);
+        astep = (uint32_t)S.a_sk;
+        akmax = (uint32_t)(S.K - 1) * astep, bkmax = (uint32_t)(S.K - 1) * (uint32_t)S.b_sk;
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            // granule G of the LDS image is written by lane `lane` of DMA instruction (wave, j)
+            const int G = (wave * NI + j) * 64 + lane;
+            if (s_kmaj) { // image [k][TM rows]; granule = rows (2p', 2p'+1) of one k, p' = p ^ 8*(k&1)
+                const int kl = G / (TM / 2), p = G % (TM / 2);
+                const int row = 2 * (p ^ (8 * (kl & 1)));
+                aoff[j] = (uint32_t)min(row, S.mr - 1);
+                akq[j] = (uint32_t)kl * astep;
+            } else { // image [TM rows][16 k]; granule slot gs of row holds k = 2*(gs ^ ((row>>1)&7)), +1
+                const int row = G >> 3, gs = G & 7;
+                aoff[j] = (uint32_t)min(row, S.mr - 1) * (uint32_t)S.a_sr;
+                akq[j] = (uint32_t)(2 * (gs ^ ((row >> 1) & 7)));
+            }
         }
+        colmask = 0;
 #pragma unroll
         for (int q = 0; q < CF; q++) {
             int cc = wave * (CF * 16) + q * 16 + c - S.tc0;
-            const bool ok = cc >= 0 && cc < S.nc;
-            const int ccl = min(max(cc, 0), S.nc - 1);
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                int k = kb + 4 * s + g;
-                bmask |= (uint32_t)(ok && k < S.K) << (q * 4 + s);
-                bnxt[q][s] = B[(int64_t)min(k, S.K - 1) * S.b_sk + (int64_t)ccl * S.b_sc];
-            }
+            colmask |= (uint32_t)(cc >= 0 && cc < S.nc) << q;
+            boff[q] = (uint32_t)min(max(cc, 0), S.nc - 1) * (uint32_t)S.b_sc;
         }
     };
-    // registers -> LDS buffer (A) / current B fragments, invalid elements zeroed
-    auto commit = [&](const GSeg &S, double *As) {
-        if (S.a_sk != 1) {
+    uint32_t bmask = 0;
+    bool bmasked = false;
+    // issue the DMA of the A chunk at k offset kb into LDS buffer `As`, and the B loads into bnxt
+    auto fetch = [&](const GSeg &S, int kb, double *As) __attribute__((always_inline)) {
+        const uint32_t kbo = (uint32_t)kb * astep;
 #pragma unroll
-            for (int i = 0; i < NA; i++) {
-                int e = tid + NT * i;
-                As[(e / TM) * LDZT + (e % TM)] = ((amask >> i) & 1) ? areg[i] : 0.0;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NA; i++) {
-                int e = tid + NT * i;
-                As[(e >> 4) * LDX + (e & 15)] = ((amask >> i) & 1) ? areg[i] : 0.0;
+        for (int j = 0; j < NI; j++) {
+            if (NG % NT == 0 || (wave * NI + j) * 64 < NG) { // whole DMA instruction inside the image
+                const uint32_t off = aoff[j] + min(kbo + akq[j], akmax);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sA + off),
+                                                 (__attribute__((address_space(3))) void *)(As + (wave * NI + j) * 128),
+                                                 16, 0, 0);
             }
         }
+        const uint32_t bstep = (uint32_t)S.b_sk;
+#pragma unroll
+        for (int q = 0; q < CF; q++) {
+            uint32_t ko = (uint32_t)(kb + g) * bstep;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                bnxt[q][s] = sB[boff[q] + min(ko, bkmax)];
+                ko += 4 * bstep;
+            }
+        }
+        bmasked = !cols_full || kb + 16 > S.K; // the k tail is neutralised on the B side
+        if (bmasked) {
+            bmask = 0;
+#pragma unroll
+            for (int q = 0; q < CF; q++)
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+                    bmask |= (uint32_t)(((colmask >> q) & 1) && kb + 4 * s + g < S.K) << (q * 4 + s);
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < CF; q++)
 #pragma unroll
             for (int s = 0; s < 4; s++)
-                bcur[q][s] = ((bmask >> (q * 4 + s)) & 1) ? bnxt[q][s] : 0.0;
+                bcur[q][s] = (!bmasked || ((bmask >> (q * 4 + s)) & 1)) ? bnxt[q][s] : 0.0;
+    };
+    // the MFMA block: all TMF x CF fragments, branch-free
+    // Pin the issue order inside the MFMA block: LDS reads run LEAD fragments ahead of the MFMAs that consume
+    // them.  Left alone, hipcc hoists all 4*TMF ds_reads to the top of the block (2 VGPRs each), which at
+    // TMF = 16 exceeds the 256-VGPR budget of two waves per SIMD and spills inside the loop.
+    auto pin_schedule = [&]() __attribute__((always_inline)) {
+        constexpr int LEAD = 6, NRD = 4 * TMF;
+        __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0); // DS reads
+#pragma unroll
+        for (int i = 0; i < NRD - LEAD; i++) {
+            __builtin_amdgcn_sched_group_barrier(0x008, CF, 0); // MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, LEAD * CF, 0);
+    };
+    // The MFMA block: all TMF x CF fragments in ONE basic block for both image layouts (a branch over the
+    // layouts would give every accumulator two definitions and hipcc then keeps two copies of the tile).
+    //   rowmaj image: (row, k) at row*16 + 2*((k>>1) ^ ((row>>1)&7)) + (k&1)
+    //   kmaj   image: (row, k) at k*TM + (row ^ 16*(k&1))
+    // with row = f*16 + c, k = 4s + g.  Per k-step s a lane needs two bases (even / odd fragment, they differ
+    // only for the kmaj swizzle) and a wave-uniform fragment stride.
+    auto compute = [&](const double *As, bool kmaj) __attribute__((always_inline)) {
+        const int sw = (c >> 1) & 7;
+        const double *pe[4], *po[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const int o_row = c * 16 + 2 * ((2 * s + (g >> 1)) ^ sw) + (g & 1);
+            const int o_k = (4 * s + g) * TM + c;
+            pe[s] = As + (kmaj ? o_k + 16 * (g & 1) : o_row);
+            po[s] = As + (kmaj ? o_k - 16 * (g & 1) : o_row);
+        }
+        const int sf = kmaj ? 16 : 256;
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int f = 0; f < TMF; f++) {
+                double a = ((f & 1) ? po[s] : pe[s])[f * sf];
+#pragma unroll
+                for (int q = 0; q < CF; q++)
+                    acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][s], acc[f][q], 0, 0, 0);
+            }
+        pin_schedule();
     };
 
     uint32_t si = item.seg_begin;
     if (si < item.seg_end) {
         GSeg S = segs[si];
         int kb = 0, buf = 0;
-        fetch(S, 0);
-        commit(S, lds);
-        __syncthreads();
+        enter(S);
+        fetch(S, 0, lds);
+        commit();
+        bool cur_kmaj = s_kmaj;
+        __syncthreads(); // drains the DMA (vmcnt(0)) and publishes the image
         while (true) {
-            // next chunk of the flattened (segment, k) walk
             uint32_t nsi = si;
             int nkb = kb + 16;
             if (nkb >= S.K)
                 nsi = si + 1, nkb = 0;
             const bool more = nsi < item.seg_end;
-            GSeg Sn = S;
-            if (more && nsi != si)
-                Sn = segs[nsi];
-            if (more)
-                fetch(Sn, nkb);
-            __builtin_amdgcn_sched_barrier(0); // loads issued; nothing below may move above them
-            // ---- compute the chunk resident in LDS ----
-            {
-                const double *As = lds + buf * ABUF;
-                const bool kmaj = (S.a_sk != 1);
-                const int lsr = kmaj ? 1 : LDX, lsk = kmaj ? LDZT : 1;
-                // branch-free: all TMF x CF fragments every chunk (rows/cols outside the segment's window are
-                // zero in LDS / in the B registers).  Any branch here splits the block and makes hipcc shuttle
-                // the accumulators between VGPRs and AGPRs around every fragment group (drains the MFMA pipe).
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-#pragma unroll
-                    for (int f = 0; f < TMF; f++) {
-                        double a = As[(f * 16 + c) * lsr + (4 * s + g) * lsk];
-#pragma unroll
-                        for (int q = 0; q < CF; q++)
-                            acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][s], acc[f][q], 0, 0, 0);
-                    }
-                }
+            if (more && nsi != si) {
+                S = segs[nsi];
+                enter(S);
             }
-            __builtin_amdgcn_sched_barrier(0); // the prefetched chunk is consumed only after the MFMAs
+            if (more)
+                fetch(S, nkb, lds + (buf ^ 1) * ABUF);
+            __builtin_amdgcn_sched_barrier(0); // loads issued; nothing below may move above them
+            compute(lds + buf * ABUF, cur_kmaj);
+            __builtin_amdgcn_sched_barrier(0);
             if (!more)
                 break;
             buf ^= 1;
-            commit(Sn, lds + buf * ABUF);
+            commit();
+            cur_kmaj = s_kmaj;
             __syncthreads();
-            S = Sn, si = nsi, kb = nkb;
+            si = nsi, kb = nkb;
         }
     }
     // ---- store the tile ----
