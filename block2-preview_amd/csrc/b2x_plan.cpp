@@ -37,6 +37,22 @@ std::vector<int> balanced_cuts(int total, int max_piece) {
     return cuts;
 }
 
+// Row cuts for the grouped-GEMM kernel, whose tile-height variants are multiples of 64 rows (<= 256):
+// split `total` into ceil(U/4) pieces of near-equal size in units of 64 (U = ceil(total/64)), so the issued
+// rows are 64*U (the minimum) and no piece is needlessly small.
+std::vector<int> unit_cuts(int total) {
+    const int U = ceil_div(total, 64), n = ceil_div(U, 4);
+    std::vector<int> cuts{0};
+    int pos = 0;
+    for (int i = 0; i < n; i++) {
+        int units = U / n + (i < U % n ? 1 : 0);
+        pos = std::min(total, pos + units * 64);
+        cuts.push_back(pos);
+    }
+    cuts.back() = total;
+    return cuts;
+}
+
 } // namespace
 
 int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len, uint64_t arena_len,
@@ -304,7 +320,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     // ---- two-stage path: W = alpha X op(Y) to scratch, then psi' tiles += op(Z) W ---------------
     uint64_t gg_macs = 0;
     if (!big.empty()) {
-        const int TM = kGGTileM, TN = kGGTileN;
+        const int TN = kGGTileN;
         const uint64_t budget = (uint64_t)(opt && opt->scratch_mb > 0 ? opt->scratch_mb : 4096) * (1u << 17);
         // work in component order; a super-step closes when the W scratch budget is reached
         struct PW {
@@ -322,7 +338,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             // stage 0: tiles of every W
             for (const PW &pw : cur) {
                 const b2x_pair &p = pairs[win[pw.wi].pair];
-                std::vector<int> rc = balanced_cuts(p.k1, TM), cc = balanced_cuts(p.n0, TN);
+                std::vector<int> rc = unit_cuts(p.k1), cc = balanced_cuts(p.n0, TN);
                 for (size_t a = 0; a + 1 < rc.size(); a++)
                     for (size_t b = 0; b + 1 < cc.size(); b++) {
                         GSeg g{};
@@ -365,7 +381,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
                 std::vector<int> rc;
                 for (size_t bi = 0; bi + 1 < bounds.size(); bi++) {
-                    std::vector<int> sub = balanced_cuts(bounds[bi + 1] - bounds[bi], TM);
+                    std::vector<int> sub = unit_cuts(bounds[bi + 1] - bounds[bi]);
                     for (size_t k = 0; k + 1 < sub.size(); k++)
                         rc.push_back(bounds[bi] + sub[k]);
                 }
