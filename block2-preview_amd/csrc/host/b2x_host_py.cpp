@@ -4,6 +4,7 @@
 // GMatrix arguments are numpy arrays (operators: 2-D float64, C-contiguous) or integer element offsets
 // (psi / psi' operands, which block2 records "from null").
 #include "b2x_host.hpp"
+#include "b2x_symbolic_py.hpp"
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -107,6 +108,7 @@ PYBIND11_MODULE(b2x_host, m) {
              },
              py::arg("ket"), py::arg("conv_thrd") = 5E-6, py::arg("max_iter") = 5000, py::arg("soft_max_iter") = -1,
              py::arg("deflation_min_size") = 2, py::arg("deflation_max_size") = 50, py::arg("iprint") = false);
+    b2xh::bind_symbolic(m);
     m.def("device_init", [](int ordinal) { check(b2x_device_init(ordinal)); }, py::arg("ordinal") = 0);
     m.def("small_eigs", [](std::vector<double> a, int n) {
         std::vector<double> w;

@@ -1,0 +1,233 @@
+// b2x_symbolic_py.hpp — pybind glue for the symbolic -> numeric host layer (b2x_symbolic.hpp).
+// A SymbolicEffectiveHamiltonian is assembled from the named arrays of an effective-Hamiltonian fixture
+// (oracle/ref_dump.cpp `eham=`; read with planfile.read_arrays): operator infos, operator tensors, the term list
+// of H_eff, wavefunction infos and the operator data arena.
+#pragma once
+#include "b2x_symbolic.hpp"
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+namespace b2xh {
+namespace py = pybind11;
+
+struct SymEHBase {
+    virtual ~SymEHBase() = default;
+    virtual py::dict wfn_cinfo() const = 0;
+    virtual void precompute() = 0;
+    virtual void post_precompute() = 0;
+    virtual size_t n_pairs() const = 0;
+    virtual size_t nflop() const = 0;
+    virtual py::array pairs() const = 0;
+    virtual void record() = 0;
+    virtual void apply(py::array_t<double, py::array::c_style> b, py::array_t<double, py::array::c_style> c,
+                       double factor) = 0;
+    virtual py::tuple eigs(std::vector<double> ket, double conv_thrd, int max_iter) = 0;
+};
+
+template <typename S> struct SymEH : SymEHBase {
+    typedef SparseMatrixInfo<S> Info;
+    std::shared_ptr<SymbolicEffectiveHamiltonian<S>> h;
+    py::array_t<double> arena; // keeps the operator data alive
+    template <typename T> static const T *arr(const py::dict &d, const std::string &k, size_t *n = nullptr) {
+        if (!d.contains(k.c_str()))
+            throw std::runtime_error("fixture lacks array '" + k + "'");
+        py::array a = py::array::ensure(d[k.c_str()]);
+        if (a.itemsize() != (py::ssize_t)sizeof(T))
+            throw std::runtime_error("array '" + k + "' has the wrong element size");
+        if (n)
+            *n = (size_t)a.size();
+        return (const T *)a.data();
+    }
+    static std::shared_ptr<Info> info(const py::dict &d, int id, std::map<int, std::shared_ptr<Info>> &cache) {
+        auto it = cache.find(id);
+        if (it != cache.end())
+            return it->second;
+        const std::string pre = "info." + std::to_string(id);
+        size_t n;
+        const uint64_t *q = arr<uint64_t>(d, pre + ".quanta", &n);
+        const uint32_t *nb = arr<uint32_t>(d, pre + ".nbra"), *nk = arr<uint32_t>(d, pre + ".nket"),
+                       *nt = arr<uint32_t>(d, pre + ".ntot");
+        const uint64_t *meta = arr<uint64_t>(d, pre + ".meta");
+        auto r = std::make_shared<Info>();
+        r->n = (int)n;
+        for (size_t i = 0; i < n; i++) {
+            r->quanta.push_back(S(q[i]));
+            r->n_states_bra.push_back(nb[i]), r->n_states_ket.push_back(nk[i]), r->n_states_total.push_back(nt[i]);
+        }
+        r->delta_quantum = S(meta[0]), r->is_fermion = meta[1] != 0, r->is_wavefunction = meta[2] != 0;
+        // tensor-product connection info of a delayed enlarged operator (built by the blocking layer, taken as data)
+        if (d.contains((pre + ".cinfo.n").c_str())) {
+            auto ci = std::make_shared<typename Info::ConnectionInfo>();
+            const int64_t *nn = arr<int64_t>(d, pre + ".cinfo.n");
+            for (int i = 0; i < 5; i++)
+                ci->n[i] = (int)nn[i];
+            ci->nc = (int)nn[5];
+            size_t nq, nc;
+            const uint64_t *cq = arr<uint64_t>(d, pre + ".cinfo.quanta", &nq);
+            const uint32_t *ix = arr<uint32_t>(d, pre + ".cinfo.idx");
+            const uint64_t *st = arr<uint64_t>(d, pre + ".cinfo.stride", &nc);
+            const double *f = arr<double>(d, pre + ".cinfo.factor");
+            const uint32_t *ia = arr<uint32_t>(d, pre + ".cinfo.ia"), *ib = arr<uint32_t>(d, pre + ".cinfo.ib"),
+                           *ic = arr<uint32_t>(d, pre + ".cinfo.ic");
+            for (size_t i = 0; i < nq; i++)
+                ci->quanta.push_back(S(cq[i])), ci->idx.push_back(ix[i]);
+            for (size_t i = 0; i < nc; i++) {
+                ci->stride.push_back(st[i]), ci->factor.push_back(f[i]);
+                ci->ia.push_back(ia[i]), ci->ib.push_back(ib[i]), ci->ic.push_back(ic[i]);
+            }
+            r->cinfo = ci;
+        }
+        cache[id] = r;
+        return r;
+    }
+    std::shared_ptr<OperatorTensor<S>> tensor(const py::dict &d, const std::string &pre,
+                                              std::map<int, std::shared_ptr<Info>> &cache) {
+        auto t = std::make_shared<OperatorTensor<S>>();
+        size_t n;
+        const int64_t *iid = arr<int64_t>(d, pre + ".info", &n), *len = arr<int64_t>(d, pre + ".len"),
+                      *off = arr<int64_t>(d, pre + ".off");
+        const double *fac = arr<double>(d, pre + ".factor");
+        for (size_t i = 0; i < n; i++) {
+            auto m = std::make_shared<SparseMatrix<S>>();
+            m->info = info(d, (int)iid[i], cache);
+            m->factor = fac[i];
+            m->total_memory = len[i] < 0 ? 0 : (size_t)len[i];
+            m->data = off[i] < 0 ? nullptr : arena.mutable_data() + off[i];
+            t->ops.push_back(m);
+        }
+        return t;
+    }
+    explicit SymEH(const py::dict &d) {
+        arena = py::array_t<double>(py::array::ensure(d["arena"]));
+        std::map<int, std::shared_ptr<Info>> cache;
+        const uint64_t *lab = arr<uint64_t>(d, "labels");
+        std::vector<std::pair<S, std::shared_ptr<Info>>> li, ri;
+        size_t nl, nr;
+        const uint64_t *ll = arr<uint64_t>(d, "linfos.label", &nl), *lid = arr<uint64_t>(d, "linfos.info");
+        const uint64_t *rl = arr<uint64_t>(d, "rinfos.label", &nr), *rid = arr<uint64_t>(d, "rinfos.info");
+        for (size_t i = 0; i < nl; i++)
+            li.emplace_back(S(ll[i]), info(d, (int)lid[i], cache));
+        for (size_t i = 0; i < nr; i++)
+            ri.emplace_back(S(rl[i]), info(d, (int)rid[i], cache));
+        auto ket = info(d, (int)arr<uint64_t>(d, "ket.info")[0], cache);
+        auto bra = info(d, (int)arr<uint64_t>(d, "bra.info")[0], cache);
+        if (ket == bra) { // the reference shares one info object; the wavefunction connection info hangs off ket
+            bra = std::make_shared<Info>(*ket);
+        }
+        auto lopt = tensor(d, "lopt", cache), ropt = tensor(d, "ropt", cache);
+        const uint64_t *del = arr<uint64_t>(d, "tensor.delayed");
+        if (del[0] || del[1]) {
+            auto &dt = del[0] ? lopt : ropt;
+            dt->type = OperatorTensorTypes::Delayed;
+            dt->lopt = tensor(d, "dopt.l", cache), dt->ropt = tensor(d, "dopt.r", cache);
+        }
+        size_t nt;
+        const int64_t *ty = arr<int64_t>(d, "expr.type", &nt), *cj = arr<int64_t>(d, "expr.conj"),
+                      *ea = arr<int64_t>(d, "expr.a"), *eb = arr<int64_t>(d, "expr.b"), *d0 = arr<int64_t>(d, "expr.d0"),
+                      *d1 = arr<int64_t>(d, "expr.d1"), *dc = arr<int64_t>(d, "expr.dconj");
+        const double *ef = arr<double>(d, "expr.factor");
+        std::vector<OpTerm> expr(nt);
+        for (size_t i = 0; i < nt; i++) {
+            expr[i].type = ty[i] ? OpTypes::SumProd : OpTypes::Prod;
+            expr[i].factor = ef[i], expr[i].conj = (uint8_t)cj[i];
+            expr[i].a = (int)ea[i], expr[i].b = (int)eb[i], expr[i].d0 = (int)d0[i], expr[i].d1 = (int)d1[i];
+            expr[i].dconj = (uint8_t)dc[i];
+        }
+        // operator sub-labels (conj flag, combined delta quantum): from the reference's get_uniq_sub_labels
+        // (partition.hpp, MPO layer) — taken as data, stored with the fixture as the keys of its connection info
+        const int64_t *nn = arr<int64_t>(d, "wfn_cinfo.n");
+        const uint64_t *sq = arr<uint64_t>(d, "wfn_cinfo.quanta");
+        std::vector<std::pair<uint8_t, S>> subdq;
+        for (int k = 0; k < (int)nn[4]; k++) {
+            uint8_t c = 0;
+            while (c < 3 && k >= (int)nn[c + 1])
+                c++;
+            subdq.emplace_back(c, S(sq[k]));
+        }
+        size_t nd;
+        const double *dg = arr<double>(d, "diag", &nd);
+        h = std::make_shared<SymbolicEffectiveHamiltonian<S>>(li, ri, lopt, ropt, expr, ket, bra, S(lab[2]), subdq,
+                                                              std::vector<double>(dg, dg + nd));
+    }
+    py::dict wfn_cinfo() const override {
+        const auto &c = *h->wfn_info;
+        py::dict r;
+        std::vector<uint64_t> q;
+        for (auto x : c.quanta)
+            q.push_back(x.data);
+        r["n"] = std::vector<int64_t>{c.n[0], c.n[1], c.n[2], c.n[3], c.n[4], c.nc};
+        r["quanta"] = q, r["idx"] = c.idx, r["stride"] = c.stride, r["factor"] = c.factor;
+        r["ia"] = c.ia, r["ib"] = c.ib, r["ic"] = c.ic;
+        return r;
+    }
+    void precompute() override { h->precompute(); }
+    void post_precompute() override { h->post_precompute(); }
+    size_t n_pairs() const override { return h->tf->opf->seq->pairs.size(); }
+    size_t nflop() const override { return h->tf->opf->seq->nflop; }
+    // the recorded pairs with operator pointers expressed as offsets into the fixture's arena (no device needed)
+    py::array pairs() const override {
+        const auto &sq = *h->tf->opf->seq;
+        std::vector<b2x_pair> p = sq.pairs;
+        for (size_t i = 0; i < p.size(); i++) {
+            p[i].y_off = (uint64_t)(sq.y_ptr[i] - arena.data());
+            p[i].z_off = (uint64_t)(sq.z_ptr[i] - arena.data());
+        }
+        py::array_t<uint8_t> a(p.size() * sizeof(b2x_pair));
+        std::memcpy(a.mutable_data(), p.data(), p.size() * sizeof(b2x_pair));
+        return a;
+    }
+    // record the plan only (tensor_product_multiply with null-based wavefunctions), no upload
+    void record() override {
+        auto seq = h->tf->opf->seq;
+        if (!seq->pairs.empty())
+            return;
+        SparseMatrix<S> cmat, vmat;
+        cmat.info = h->ket_info, vmat.info = h->bra_info;
+        cmat.data = vmat.data = (double *)0;
+        h->tf->tensor_product_multiply(h->expr, *h->lopt, *h->ropt, cmat, vmat, h->opdq);
+    }
+    void apply(py::array_t<double, py::array::c_style> b, py::array_t<double, py::array::c_style> c,
+               double factor) override {
+        (*h)(GMatrix(b.mutable_data(), (int)b.size(), 1), GMatrix(c.mutable_data(), (int)c.size(), 1), factor);
+    }
+    py::tuple eigs(std::vector<double> ket, double conv_thrd, int max_iter) override {
+        auto r = h->eigs(ket, conv_thrd, max_iter);
+        return py::make_tuple(std::get<0>(r), std::get<1>(r), std::get<2>(r), std::get<3>(r),
+                              py::array_t<double>(ket.size(), ket.data()));
+    }
+};
+
+inline void bind_symbolic(py::module_ &m) {
+    py::class_<SymEHBase, std::shared_ptr<SymEHBase>>(m, "SymbolicEffectiveHamiltonian")
+        .def(py::init([](const std::string &sym, const py::dict &d) -> std::shared_ptr<SymEHBase> {
+            if (sym == "sz")
+                return std::make_shared<SymEH<SZ>>(d);
+            if (sym == "su2")
+                return std::make_shared<SymEH<SU2>>(d);
+            throw std::runtime_error("symmetry must be 'sz' or 'su2'");
+        }))
+        .def("wfn_cinfo", &SymEHBase::wfn_cinfo)
+        .def("precompute", &SymEHBase::precompute)
+        .def("post_precompute", &SymEHBase::post_precompute)
+        .def_property_readonly("n_pairs", &SymEHBase::n_pairs)
+        .def_property_readonly("nflop", &SymEHBase::nflop)
+        .def("pairs", &SymEHBase::pairs)
+        .def("record", &SymEHBase::record)
+        .def("__call__", &SymEHBase::apply, py::arg("b"), py::arg("c"), py::arg("factor") = 1.0)
+        .def("eigs", &SymEHBase::eigs, py::arg("ket"), py::arg("conv_thrd") = 5E-6, py::arg("max_iter") = 5000);
+    // label algebra exposed for unit tests (packed 64-bit in / out)
+    m.def("su2_add", [](uint64_t a, uint64_t b) { return (SU2(a) + SU2(b)).data; });
+    m.def("su2_combine", [](uint64_t dq, uint64_t bra, uint64_t ket) { return SU2(dq).combine(SU2(bra), SU2(ket)).data; });
+    m.def("su2_get_bra", [](uint64_t a, uint64_t dq) { return SU2(a).get_bra(SU2(dq)).data; });
+    m.def("su2_make", [](int n, int tl, int t, int pg) { return SU2(n, tl, t, pg).data; });
+    m.def("sz_make", [](int n, int t, int pg) { return SZ(n, t, pg).data; });
+    m.def("sz_add", [](uint64_t a, uint64_t b) { return (SZ(a) + SZ(b)).data; });
+    m.def("sz_neg", [](uint64_t a) { return (-SZ(a)).data; });
+    m.def("wigner_6j", [](int a, int b, int c, int d, int e, int f) { return (double)CG<SU2>().wigner_6j(a, b, c, d, e, f); });
+    m.def("wigner_9j", [](int a, int b, int c, int d, int e, int f, int g, int h, int i) {
+        return (double)CG<SU2>().wigner_9j_2j(a, b, c, d, e, f, g, h, i);
+    });
+}
+
+} // namespace b2xh

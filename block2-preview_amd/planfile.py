@@ -117,3 +117,26 @@ def read_struct_npz(fn):
     pf.arena_len, pf.max_work = int(z["arena_len"]), int(z["max_work"])
     pf.meta = z["meta"].copy()
     return pf
+
+
+_ARR_DT = {0: "<u8", 1: "<i8", 2: "<f8", 3: "<u4", 4: "u1"}
+
+
+def read_arrays(fn):
+    """Named-array container B2XARR01 (oracle/ref_dump.cpp: effective-Hamiltonian level fixtures) -> dict."""
+    raw = open(fn, "rb").read()
+    if raw[:8] != b"B2XARR01":
+        raise ValueError("%s: not a B2XARR01 file" % fn)
+    pos, out = 8, {}
+    while pos < len(raw):
+        ln = int(np.frombuffer(raw, "<u4", 1, pos)[0])
+        pos += 4
+        name = raw[pos:pos + ln].decode()
+        pos += ln
+        dt = _ARR_DT[raw[pos]]
+        pos += 1
+        cnt = int(np.frombuffer(raw, "<u8", 1, pos)[0])
+        pos += 8
+        out[name] = np.frombuffer(raw, dt, cnt, pos).copy()
+        pos += cnt * np.dtype(dt).itemsize
+    return out

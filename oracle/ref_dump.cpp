@@ -14,6 +14,7 @@
  * usage: ref_dump <fcidump|hubbard:L:t:U> <su2|sz> <M> <n_sweeps> <outprefix> [key=value ...]
  *   dump=<sweep>:<site>[,<sweep>:<site>...]  plans to capture with data
  *   struct=<sweep>:<site>[,...]              plans to capture WITHOUT data (structure only)
+ *   eham=<sweep>:<site>[,...]                effective-Hamiltonian level fixtures (infos, tensors, expression)
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
  */
 #include "block2_core.hpp"
@@ -26,8 +27,112 @@ using namespace block2;
 using namespace std;
 
 struct DumpSpec {
-    set<pair<int, int>> with_data, structure;
+    set<pair<int, int>> with_data, structure, eham;
     string prefix;
+};
+
+
+// ---- named-array container (B2XARR01) for effective-Hamiltonian level fixtures ------------------------
+// record: u32 name_len, name, u8 dtype (0 = u64, 1 = i64, 2 = f64, 3 = u32, 4 = u8), u64 count, data
+struct ArrayFile {
+    FILE *f;
+    explicit ArrayFile(const string &fn) : f(fopen(fn.c_str(), "wb")) { fwrite("B2XARR01", 1, 8, f); }
+    ~ArrayFile() { fclose(f); }
+    void put(const string &name, uint8_t dt, size_t esz, const void *data, uint64_t n) {
+        uint32_t l = (uint32_t)name.size();
+        fwrite(&l, 4, 1, f), fwrite(name.data(), 1, l, f), fwrite(&dt, 1, 1, f), fwrite(&n, 8, 1, f);
+        if (n)
+            fwrite(data, esz, n, f);
+    }
+    void u64(const string &n, const vector<uint64_t> &v) { put(n, 0, 8, v.data(), v.size()); }
+    void i64(const string &n, const vector<int64_t> &v) { put(n, 1, 8, v.data(), v.size()); }
+    void f64(const string &n, const vector<double> &v) { put(n, 2, 8, v.data(), v.size()); }
+    void f64(const string &n, const double *p, size_t c) { put(n, 2, 8, p, c); }
+    void u32(const string &n, const vector<uint32_t> &v) { put(n, 3, 4, v.data(), v.size()); }
+    void u8(const string &n, const vector<uint8_t> &v) { put(n, 4, 1, v.data(), v.size()); }
+};
+
+// Everything the symbolic -> numeric layer of one EffectiveHamiltonian consumes and produces:
+// operator infos, operator tensors (incl. the delayed left/right enlarged operators), the expression of
+// H_eff, the wavefunction infos, and the reference's own ConnectionInfo / plan / sigma for them.
+template <typename S> struct EhamDump {
+    typedef double FL;
+    ArrayFile af;
+    map<const SparseMatrixInfo<S> *, int> info_ids;
+    set<int> cinfo_done;
+    vector<pair<const double *, size_t>> ranges; // operator data ranges
+    explicit EhamDump(const string &fn) : af(fn) {}
+    template <typename CI> void put_cinfo(const string &pre, const shared_ptr<CI> &ci) {
+        vector<int64_t> nn(ci->n, ci->n + 5);
+        nn.push_back(ci->nc);
+        af.i64(pre + ".n", nn);
+        vector<uint64_t> q(ci->n[4]);
+        vector<uint32_t> idx(ci->n[4]);
+        for (int i = 0; i < ci->n[4]; i++)
+            q[i] = ci->quanta[i].data, idx[i] = ci->idx[i];
+        af.u64(pre + ".quanta", q), af.u32(pre + ".idx", idx);
+        af.u64(pre + ".stride", vector<uint64_t>(ci->stride, ci->stride + ci->nc));
+        af.f64(pre + ".factor", ci->factor, ci->nc);
+        af.u32(pre + ".ia", vector<uint32_t>(ci->ia, ci->ia + ci->nc));
+        af.u32(pre + ".ib", vector<uint32_t>(ci->ib, ci->ib + ci->nc));
+        af.u32(pre + ".ic", vector<uint32_t>(ci->ic, ci->ic + ci->nc));
+    }
+    int info_id(const shared_ptr<SparseMatrixInfo<S>> &info, bool with_cinfo) {
+        auto it = info_ids.find(info.get());
+        if (it != info_ids.end()) {
+            if (with_cinfo && info->cinfo != nullptr && !cinfo_done.count(it->second)) {
+                cinfo_done.insert(it->second);
+                put_cinfo("info." + Parsing::to_string(it->second) + ".cinfo", info->cinfo);
+            }
+            return it->second;
+        }
+        int id = (int)info_ids.size();
+        info_ids[info.get()] = id;
+        string pre = "info." + Parsing::to_string(id);
+        vector<uint64_t> q(info->n);
+        vector<uint32_t> nb(info->n), nk(info->n), nt(info->n);
+        for (int i = 0; i < info->n; i++)
+            q[i] = info->quanta[i].data, nb[i] = info->n_states_bra[i], nk[i] = info->n_states_ket[i],
+            nt[i] = info->n_states_total[i];
+        af.u64(pre + ".quanta", q), af.u32(pre + ".nbra", nb), af.u32(pre + ".nket", nk), af.u32(pre + ".ntot", nt);
+        af.u64(pre + ".meta", vector<uint64_t>{info->delta_quantum.data, (uint64_t)info->is_fermion,
+                                               (uint64_t)info->is_wavefunction, (uint64_t)info->get_total_memory()});
+        if (with_cinfo && info->cinfo != nullptr) {
+            cinfo_done.insert(id);
+            put_cinfo(pre + ".cinfo", info->cinfo);
+        }
+        return id;
+    }
+    // one operator tensor: per op (info id, factor, has data) + data range; returns the op order
+    vector<shared_ptr<OpExpr<S>>> put_tensor(const string &pre, const shared_ptr<OperatorTensor<S, FL>> &t,
+                                             bool with_cinfo, vector<const double *> &ptrs) {
+        vector<shared_ptr<OpExpr<S>>> order;
+        vector<int64_t> iid, has;
+        vector<double> fac;
+        for (auto &kv : t->ops) {
+            order.push_back(kv.first);
+            iid.push_back(info_id(kv.second->info, with_cinfo));
+            fac.push_back(kv.second->factor);
+            bool hd = kv.second->data != nullptr && kv.second->total_memory != 0;
+            has.push_back(hd ? (int64_t)kv.second->total_memory : -1);
+            ptrs.push_back(hd ? kv.second->data : nullptr);
+            if (hd)
+                ranges.push_back(make_pair((const double *)kv.second->data, (size_t)kv.second->total_memory));
+        }
+        af.i64(pre + ".info", iid), af.f64(pre + ".factor", fac), af.i64(pre + ".len", has);
+        return order;
+    }
+    // position of symbol x in the dumped op order of tensor t (lookup by the tensor's own hash / equality)
+    static int find_op(const shared_ptr<OperatorTensor<S, FL>> &t, const vector<shared_ptr<OpExpr<S>>> &order,
+                       const shared_ptr<OpExpr<S>> &x) {
+        auto it = t->ops.find(x);
+        if (it == t->ops.end())
+            return -1;
+        for (size_t i = 0; i < order.size(); i++)
+            if (order[i].get() == it->first.get())
+                return (int)i;
+        return -1;
+    }
 };
 
 template <typename S> struct Dumper : CallbackKernel {
@@ -45,12 +150,116 @@ template <typename S> struct Dumper : CallbackKernel {
             bool wd = spec.with_data.count(key), st = spec.structure.count(key);
             if (wd || st)
                 capture(isw, site, wd);
+            if (spec.eham.count(key))
+                capture_eham(isw, site);
         } else if (name == "DMRG::sweep::iter.end") {
             stringstream ss;
             ss.precision(15);
             ss << "SITE_ENERGY " << isw << " " << site << " " << dmrg->sweep_energies.back()[0];
             log.push_back(ss.str());
         }
+    }
+
+    void capture_eham(int isw, int site) const {
+        auto h = dmrg->current_eff_ham;
+        stringstream fn;
+        fn << spec.prefix << ".sw" << isw << ".site" << site << ".eham";
+        EhamDump<S> ed(fn.str());
+        ArrayFile &af = ed.af;
+        S cdq = h->ket->info->delta_quantum, vdq = h->bra->info->delta_quantum;
+        af.u64("labels", vector<uint64_t>{cdq.data, vdq.data, h->opdq.data, h->hop_left_vacuum.data});
+        af.f64("const_e", vector<double>{(double)dmrg->me->mpo->const_e});
+        // operator infos
+        vector<uint64_t> ll, li, rl, ri;
+        for (auto &p : h->left_op_infos)
+            ll.push_back(p.first.data), li.push_back((uint64_t)ed.info_id(p.second, false));
+        for (auto &p : h->right_op_infos)
+            rl.push_back(p.first.data), ri.push_back((uint64_t)ed.info_id(p.second, false));
+        af.u64("linfos.label", ll), af.u64("linfos.info", li), af.u64("rinfos.label", rl), af.u64("rinfos.info", ri);
+        af.u64("ket.info", vector<uint64_t>{(uint64_t)ed.info_id(h->ket->info, false)});
+        af.u64("bra.info", vector<uint64_t>{(uint64_t)ed.info_id(h->bra->info, false)});
+        // the reference's own connection info of the wavefunction (what initialize_wfn must reproduce)
+        ed.put_cinfo("wfn_cinfo", h->wfn_infos[0]);
+        // operator tensors
+        auto lopt = h->op->lopt, ropt = h->op->ropt;
+        const bool dl = lopt->get_type() == OperatorTensorTypes::Delayed,
+                   dr = ropt->get_type() == OperatorTensorTypes::Delayed;
+        af.u64("tensor.delayed", vector<uint64_t>{(uint64_t)dl, (uint64_t)dr});
+        vector<const double *> lp, rp, dlp, drp;
+        auto lorder = ed.put_tensor("lopt", lopt, true, lp);
+        auto rorder = ed.put_tensor("ropt", ropt, true, rp);
+        vector<shared_ptr<OpExpr<S>>> dlorder, drorder;
+        shared_ptr<DelayedOperatorTensor<S, FL>> dopt = nullptr;
+        if (dl || dr) {
+            dopt = dynamic_pointer_cast<DelayedOperatorTensor<S, FL>>(dl ? lopt : ropt);
+            dlorder = ed.put_tensor("dopt.l", dopt->lopt, false, dlp);
+            drorder = ed.put_tensor("dopt.r", dopt->ropt, false, drp);
+        }
+        // arena of all operator data ranges
+        auto rg = ed.ranges;
+        sort(rg.begin(), rg.end());
+        rg.erase(unique(rg.begin(), rg.end()), rg.end());
+        vector<const double *> starts;
+        vector<uint64_t> offs;
+        uint64_t tot = 0;
+        for (auto &r : rg)
+            starts.push_back(r.first), offs.push_back(tot), tot += r.second;
+        vector<double> arena(tot);
+        for (size_t i = 0; i < rg.size(); i++)
+            memcpy(arena.data() + offs[i], rg[i].first, rg[i].second * 8);
+        af.f64("arena", arena);
+        auto offs_of = [&](const vector<const double *> &ptrs) {
+            vector<int64_t> o;
+            for (auto p : ptrs) {
+                if (p == nullptr) {
+                    o.push_back(-1);
+                    continue;
+                }
+                size_t k = lower_bound(starts.begin(), starts.end(), p) - starts.begin();
+                o.push_back((int64_t)offs[k]);
+            }
+            return o;
+        };
+        af.i64("lopt.off", offs_of(lp)), af.i64("ropt.off", offs_of(rp));
+        af.i64("dopt.l.off", offs_of(dlp)), af.i64("dopt.r.off", offs_of(drp));
+        // expression of H_eff: a sum of Prod / SumProd terms
+        vector<int64_t> ty, cj, ia, ib, d0, d1, dcj;
+        vector<double> fac;
+        auto add_term = [&](const shared_ptr<OpExpr<S>> &e) {
+            if (e->get_type() == OpTypes::SumProd) {
+                auto op = dynamic_pointer_cast<OpSumProd<S, FL>>(e);
+                ty.push_back(1), cj.push_back(op->conj), fac.push_back(op->factor);
+                ia.push_back(EhamDump<S>::find_op(lopt, lorder, op->a)), ib.push_back(EhamDump<S>::find_op(ropt, rorder, op->b));
+                d0.push_back(EhamDump<S>::find_op(dopt->lopt, dlorder, op->ops[0]));
+                d1.push_back(EhamDump<S>::find_op(dopt->ropt, drorder, op->ops[1]));
+                dcj.push_back((int64_t)op->conjs[0] | ((int64_t)op->conjs[1] << 1));
+            } else if (e->get_type() == OpTypes::Prod) {
+                auto op = dynamic_pointer_cast<OpProduct<S, FL>>(e);
+                ty.push_back(0), cj.push_back(op->conj), fac.push_back(op->factor);
+                ia.push_back(EhamDump<S>::find_op(lopt, lorder, op->a)), ib.push_back(EhamDump<S>::find_op(ropt, rorder, op->b));
+                d0.push_back(-1), d1.push_back(-1), dcj.push_back(0);
+            } else
+                assert(false);
+        };
+        auto ex = h->op->mat->data[0];
+        if (ex->get_type() == OpTypes::Sum)
+            for (auto &t : dynamic_pointer_cast<OpSum<S, FL>>(ex)->strings)
+                add_term(t);
+        else
+            add_term(ex);
+        af.i64("expr.type", ty), af.i64("expr.conj", cj), af.f64("expr.factor", fac), af.i64("expr.a", ia);
+        af.i64("expr.b", ib), af.i64("expr.d0", d0), af.i64("expr.d1", d1), af.i64("expr.dconj", dcj);
+        // data: psi, diag, reference sigma
+        size_t n = h->ket->total_memory;
+        af.f64("psi", h->ket->data, n), af.f64("diag", h->diag->data, n);
+        vector<double> sigma(h->bra->total_memory, 0.0);
+        h->precompute();
+        (*h->tf)(GMatrix<double>(h->ket->data, (MKL_INT)n, 1), GMatrix<double>(sigma.data(), (MKL_INT)sigma.size(), 1), 1.0);
+        af.u64("n_pairs", vector<uint64_t>{(uint64_t)h->tf->opf->seq->batch[0]->c.size(),
+                                           (uint64_t)(h->tf->opf->seq->batch[0]->nflop + h->tf->opf->seq->batch[1]->nflop)});
+        h->post_precompute();
+        af.f64("sigma_ref", sigma);
+        cerr << "EHAM " << fn.str() << " terms=" << ty.size() << " arena=" << tot << " psi=" << n << endl;
     }
     void capture(int isw, int site, bool with_data) const {
         auto h = dmrg->current_eff_ham;
@@ -252,6 +461,8 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
         dumper->spec.with_data = parse_pairs(kv["dump"]);
     if (kv.count("struct"))
         dumper->spec.structure = parse_pairs(kv["struct"]);
+    if (kv.count("eham"))
+        dumper->spec.eham = parse_pairs(kv["eham"]);
     callback_() = dumper;
     double tol = kv.count("tol") ? Parsing::to_double(kv["tol"]) : 1E-8;
     Timer t;

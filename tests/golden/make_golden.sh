@@ -16,3 +16,8 @@ $R $D/H10.STO6G.R1.8.FCIDUMP sz 50 6 ./h10szm50 dump=0:6,1:5,2:4 iprint=0
 #   python -c "from block2_preview_amd.planfile import *; write_struct_npz(out, read_plan(in))"
 # (the run ends with a harmless crash in the reference's teardown after all files are written)
 $R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2m250 struct=1:5,1:10,1:20,1:30,0:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
+# effective-Hamiltonian level fixtures (operator infos, operator tensors incl. delayed ones, term list of H_eff,
+# the reference's ConnectionInfo, psi, diag, sigma_ref): input AND expected output of the symbolic -> numeric layer
+$R $D/N2.STO3G.FCIDUMP sz 40 4 ./e_n2sz eham=1:5 iprint=0
+$R $D/N2.STO3G.FCIDUMP su2 60 4 ./e_n2su2 eham=0:3,1:5 iprint=0
+$R $D/H10.STO6G.R1.8.FCIDUMP sz 30 4 ./e_h10sz eham=0:5,1:4 iprint=0
