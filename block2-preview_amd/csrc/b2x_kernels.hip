@@ -151,6 +151,142 @@ __global__ __launch_bounds__(NW * 64) void hpsi_main(const DPart *__restrict__ p
 }
 
 // ------------------------------------------------------------------------------------------------
+// hpsi_wave<TMF, K1F, CF>: the wavefront-level grouped GEMM for small symmetry blocks.  ONE WAVE per work
+// item (a slice of the part list of one (TMF*16) x (CF*16) psi' tile); four independent waves share a
+// workgroup only for dispatch.  No LDS and no barriers: every MFMA operand is loaded from L2 straight into
+// its fragment register (A[row = lane&15][k = lane>>4], B[k = lane>>4][col = lane&15]), W = alpha X op(Y)
+// is chained from the stage-0 accumulator into the stage-1 B operand inside the register file, and the
+// memory latency of these short K loops is hidden by the other waves of the SIMD (<= 128 VGPRs).
+template <int TMF, int K1F, int CF>
+__global__ __launch_bounds__(256, (TMF <= 2 ? 4 : (TMF <= 4 ? 3 : 2))) void hpsi_wave(const DPart *__restrict__ parts, const DItem *__restrict__ items,
+                                                  uint32_t n_items, const double *__restrict__ arena,
+                                                  const double *__restrict__ psi, double *__restrict__ slabs) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, c = lane & 15;
+    // wave-uniform item index in an SGPR: descriptors are fetched with scalar loads, branches stay uniform
+    const uint32_t it = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (it >= n_items)
+        return;
+    const DItem item = items[it];
+
+    v4d acc[TMF][CF];
+#pragma unroll
+    for (int f = 0; f < TMF; f++)
+#pragma unroll
+        for (int q = 0; q < CF; q++)
+            acc[f][q] = v4d{0.0, 0.0, 0.0, 0.0};
+
+    for (uint32_t pi = item.part_begin; pi < item.part_end; pi++) {
+        const DPart P = parts[pi];
+        const int k0 = P.k0, mr = P.mr, nc = P.nc, tr0 = P.tr0, tc0 = P.tc0;
+        const int f_lo = tr0 >> 4, f_hi = (tr0 + mr + 15) >> 4;
+        // per-lane column of every column fragment (clamped offset + validity)
+        uint32_t yoff[CF];
+        bool cok[CF];
+#pragma unroll
+        for (int q = 0; q < CF; q++) {
+            int cc = q * 16 + c - tc0;
+            cok[q] = cc >= 0 && cc < nc;
+            yoff[q] = (uint32_t)min(max(cc, 0), nc - 1) * (uint32_t)P.scy;
+        }
+        const double *Y = arena + P.y_off;
+        for (int k1lo = 0; k1lo < P.k1; k1lo += K1F * 16) {
+            const int k1c = min(K1F * 16, P.k1 - k1lo);
+            const double *X = psi + P.x_off + (int64_t)k1lo * P.ldx;
+            const double *Z = arena + P.z_off + (int64_t)k1lo * P.skz;
+            v4d w[K1F][CF];
+#pragma unroll
+            for (int f = 0; f < K1F; f++)
+#pragma unroll
+                for (int q = 0; q < CF; q++)
+                    w[f][q] = v4d{0.0, 0.0, 0.0, 0.0};
+            // per-lane X row of every k1 fragment (rows >= k1c read a valid row; their W rows are
+            // neutralised in stage 1, where op(Z) is zeroed for k >= k1c)
+            uint32_t xoff[K1F];
+#pragma unroll
+            for (int f = 0; f < K1F; f++)
+                xoff[f] = (uint32_t)min(f * 16 + c, k1c - 1) * (uint32_t)P.ldx;
+            // ---------------- stage 0: W = X * op(Y), 16 k per trip: all loads of the trip first ----------------
+            for (int kb = 0; kb < k0; kb += 16) {
+                double b[4][CF], a[4][K1F];
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const int k = kb + 4 * s + g;
+                    const uint32_t kc = (uint32_t)min(k, k0 - 1);
+#pragma unroll
+                    for (int q = 0; q < CF; q++) {
+                        double v = Y[kc * (uint32_t)P.sky + yoff[q]];
+                        b[s][q] = (cok[q] && k < k0) ? v : 0.0; // k tail / columns outside the window: zero on the B side
+                    }
+#pragma unroll
+                    for (int f = 0; f < K1F; f++)
+                        a[s][f] = X[xoff[f] + kc];
+                }
+#pragma unroll
+                for (int s = 0; s < 4; s++)
+#pragma unroll
+                    for (int f = 0; f < K1F; f++)
+#pragma unroll
+                        for (int q = 0; q < CF; q++)
+                            w[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s][f], b[s][q], w[f][q], 0, 0, 0);
+            }
+#pragma unroll
+            for (int f = 0; f < K1F; f++)
+#pragma unroll
+                for (int q = 0; q < CF; q++)
+                    w[f][q] *= P.alpha;
+            // ---------------- stage 1: V += op(Z) * W ----------------
+            // per-lane op(Z) row of every row fragment (clamped) and its validity
+            uint32_t zoff[TMF];
+            bool rok[TMF];
+#pragma unroll
+            for (int f = 0; f < TMF; f++) {
+                const int rr = f * 16 + c - tr0;
+                rok[f] = rr >= 0 && rr < mr;
+                zoff[f] = (uint32_t)min(max(rr, 0), mr - 1) * (uint32_t)P.srz;
+            }
+#pragma unroll
+            for (int f1 = 0; f1 < K1F; f1++)
+                if (f1 * 16 < k1c) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int k = f1 * 16 + 4 * r + g;
+                        const uint32_t kz = (uint32_t)min(k, k1c - 1) * (uint32_t)P.skz;
+                        double a[TMF];
+#pragma unroll
+                        for (int f = 0; f < TMF; f++) { // fragments outside the part's row window load a valid row and are zeroed
+                            double v = Z[zoff[f] + kz];
+                            a[f] = (rok[f] && k < k1c) ? v : 0.0;
+                        }
+#pragma unroll
+                        for (int f = 0; f < TMF; f++)
+                            if (f >= f_lo && f < f_hi) {
+#pragma unroll
+                                for (int q = 0; q < CF; q++)
+                                    acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[f], w[f1][q][r], acc[f][q], 0, 0, 0);
+                            }
+                    }
+                }
+        }
+    }
+    double *slab = slabs + item.slab_off;
+#pragma unroll
+    for (int q = 0; q < CF; q++) {
+        const int col = q * 16 + c;
+        if (col < item.cols) {
+#pragma unroll
+            for (int f = 0; f < TMF; f++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    int row = f * 16 + 4 * r + g;
+                    if (row < item.rows)
+                        slab[(int64_t)row * item.cols + col] = acc[f][q][r];
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // gg_kernel<TMF, CF, NW>: grouped GEMM of the two-stage path (large sectors).  One workgroup of NW waves
 // (two per SIMD) owns a (TMF*16) x (NW*CF*16) output tile and walks a list of K-segments
 //     C[window] += A(mr x K) * B(K x nc).
@@ -497,26 +633,28 @@ __global__ __launch_bounds__(256) void vec_multidot_final_k(const double *partia
 }
 
 // ------------------------------------ launchers -----------------------------------------------
-template <int NW, int TMF, int K1F>
-static hipError_t launch_main_t(const DPart *parts, const DItem *items, uint32_t n_items, const double *arena,
+template <int TMF, int K1F, int CF>
+static hipError_t launch_wave_t(const DPart *parts, const DItem *items, uint32_t n_items, const double *arena,
                                 const double *psi, double *slabs, hipStream_t st) {
-    if (n_items == 0)
-        return hipSuccess;
-    hipLaunchKernelGGL((hpsi_main<NW, TMF, K1F>), dim3(n_items), dim3(NW * 64), 0, st, parts, items, arena, psi, slabs);
+    hipLaunchKernelGGL((hpsi_wave<TMF, K1F, CF>), dim3((n_items + 3) / 4), dim3(256), 0, st, parts, items, n_items,
+                       arena, psi, slabs);
     return hipGetLastError();
 }
 
 hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t n_items, const double *arena,
                        const double *psi, double *slabs, hipStream_t st) {
-    switch (cls) {
+    if (n_items == 0)
+        return hipSuccess;
+    switch (cls) { // (tmf, k1f, tile width / 16) of kClasses[cls]
     case 0:
-        return launch_main_t<1, 2, 2>(parts, items, n_items, arena, psi, slabs, st);
+        return launch_wave_t<2, 2, 2>(parts, items, n_items, arena, psi, slabs, st);
     case 1:
-        return launch_main_t<2, 4, 4>(parts, items, n_items, arena, psi, slabs, st);
+        return launch_wave_t<4, 2, 2>(parts, items, n_items, arena, psi, slabs, st);
     case 2:
-        return launch_main_t<4, 8, 4>(parts, items, n_items, arena, psi, slabs, st);
+        return launch_wave_t<8, 2, 2>(parts, items, n_items, arena, psi, slabs, st);
     case 3:
-        return launch_main_t<8, 16, 8>(parts, items, n_items, arena, psi, slabs, st);
+        hipLaunchKernelGGL((hpsi_main<8, 16, 8>), dim3(n_items), dim3(512), 0, st, parts, items, arena, psi, slabs);
+        return hipGetLastError();
     }
     return hipErrorInvalidValue;
 }

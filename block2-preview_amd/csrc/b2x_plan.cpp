@@ -198,19 +198,14 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         }
         // class by shape: columns decide the number of waves, rows the fragment count
         int cls;
-        if (opt && opt->tile_n > 0) {
-            cls = kNumClasses - 1;
-            for (int k = 0; k < kNumClasses; k++)
-                if (kClasses[k].nw * 16 >= opt->tile_n) {
-                    cls = k;
-                    break;
-                }
+        if (opt && opt->tile_n > 0) { // forced class (tests): 16 -> 32x32 wave, 32 -> 128x32 wave, 64 -> 64x32 wave
+            cls = opt->tile_n <= 16 ? 0 : (opt->tile_n <= 32 ? 2 : (opt->tile_n <= 64 ? 1 : 3));
         } else {
-            if (c.cols <= 16 && c.rows <= 32)
+            if (c.cols <= 32 && c.rows <= 32)
                 cls = 0;
-            else if (c.cols <= 32 && c.rows <= 64)
+            else if (c.rows <= 64)
                 cls = 1;
-            else if (c.cols <= 96 && c.rows <= 160)
+            else if (c.rows <= 128)
                 cls = 2;
             else
                 cls = 3;
@@ -286,7 +281,9 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         if (ht.parts.empty())
             continue;
         double tile_cost = std::accumulate(ht.cost.begin(), ht.cost.end(), 0.0);
-        int n_it = std::max(1, (int)std::lround(tile_cost / item_cost));
+        // a wave-kernel item occupies one wave, not a workgroup: aim for 8x more of them
+        const double ic = kClasses[ht.cls].wave ? std::max(item_cost / 8.0, 65536.0) : item_cost;
+        int n_it = std::max(1, (int)std::lround(tile_cost / ic));
         double per = tile_cost / n_it, acc = 0;
         uint32_t pb = (uint32_t)cw.parts.size(), begin = pb;
         int made = 0;

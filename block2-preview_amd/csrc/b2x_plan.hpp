@@ -80,11 +80,15 @@ struct SuperStep {
 
 static const int kGGTileM = 256, kGGTileN = 128;
 
-// kernel classes: NW waves (16 output columns each), TMF row fragments, K1F k1 fragments
+// kernel classes of the fused path.  nw = tile width / 16, tmf = tile height / 16, k1f = k1 chunk / 16.
+//   wave = true : hpsi_wave — one WAVE per work item, operands straight from L2 into MFMA fragments, no LDS,
+//                 no barriers (the wavefront-level grouped GEMM for the many small symmetry blocks)
+//   wave = false: hpsi_main — one 8-wave workgroup per item, A operands staged through LDS
 struct KClass {
     int nw, tmf, k1f;
+    bool wave;
 };
-static const KClass kClasses[] = {{1, 2, 2}, {2, 4, 4}, {4, 8, 4}, {8, 16, 8}};
+static const KClass kClasses[] = {{2, 2, 2, true}, {2, 4, 2, true}, {2, 8, 2, true}, {8, 16, 8, false}};
 static const int kNumClasses = 4;
 
 struct ClassWork {

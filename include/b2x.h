@@ -64,7 +64,6 @@ typedef struct b2x_pair {
 
 typedef struct b2x_arena b2x_arena;
 typedef struct b2x_plan b2x_plan;
-typedef struct b2x_comm b2x_comm;
 
 typedef struct b2x_plan_stats {
     uint64_t n_pairs;
