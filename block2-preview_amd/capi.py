@@ -22,7 +22,7 @@ DECLARED_SYMBOLS = [
     "b2x_arena_device_ptr", "b2x_arena_destroy",
     "b2x_plan_create", "b2x_plan_execute", "b2x_plan_get_stats", "b2x_plan_time_kernel", "b2x_plan_destroy",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
-    "b2x_vec_multi_dot", "b2x_vec_lincomb", "b2x_vec_olsen_prepare",
+    "b2x_vec_multi_dot", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
 ]
 
 

@@ -406,6 +406,51 @@ int b2x_plan_destroy(b2x_plan *p) {
     return B2X_OK;
 }
 
+// ---------------------------------------------------------------------------------- diagonal
+int b2x_diag_build(const b2x_arena *arena, size_t n_terms, const b2x_diag_term *terms, size_t diag_len, double *diag,
+                   int on_device, void *stream) {
+    if (!arena || !diag || (n_terms && !terms))
+        return fail(B2X_ERR_INVALID, "b2x_diag_build: null argument");
+    std::vector<DiagComp> comps;
+    std::vector<DiagTermD> dterms;
+    std::string err;
+    int rc = compile_diag(n_terms, terms, diag_len, arena->len, comps, dterms, err);
+    if (rc != B2X_OK)
+        return fail(rc, "b2x_diag_build: " + err);
+    if (comps.empty())
+        return B2X_OK;
+    hipStream_t st = (hipStream_t)stream;
+    DiagComp *dc = nullptr;
+    DiagTermD *dt = nullptr;
+    double *dd = diag;
+    rc = upload(&dc, comps);
+    if (rc == B2X_OK)
+        rc = upload(&dt, dterms);
+    if (rc == B2X_OK && !on_device) {
+        hipError_t e = hipMalloc((void **)&dd, diag_len * sizeof(double));
+        if (e == hipSuccess)
+            e = hipMemcpy(dd, diag, diag_len * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            rc = fail(B2X_ERR_DEVICE, std::string("b2x_diag_build: ") + hipGetErrorString(e));
+    }
+    if (rc == B2X_OK) {
+        hipError_t e = launch_diag(dc, (uint32_t)comps.size(), dt, arena->dev, dd, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st); // metadata is freed below
+        if (e == hipSuccess && !on_device)
+            e = hipMemcpy(diag, dd, diag_len * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = fail(B2X_ERR_DEVICE, std::string("b2x_diag_build: ") + hipGetErrorString(e));
+    }
+    if (dc)
+        (void)hipFree(dc);
+    if (dt)
+        (void)hipFree(dt);
+    if (!on_device && dd != diag && dd)
+        (void)hipFree(dd);
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------- vectors
 static double *g_dot_partial = nullptr, *g_dot_out = nullptr;
 static int dot_scratch() {

@@ -13,6 +13,8 @@ hipError_t launch_reduce(const DTile *tiles, uint32_t n_tiles, const double *sla
                          hipStream_t st);
 hipError_t launch_generic(const b2x_pair *pairs, uint32_t n_pairs, const double *arena, const double *psi,
                           double *sigma, double scale, hipStream_t st);
+hipError_t launch_diag(const DiagComp *comps, uint32_t n_comps, const DiagTermD *terms, const double *arena, double *diag,
+                       hipStream_t st);
 hipError_t launch_axpy(double a, const double *x, double *y, size_t n, hipStream_t st);
 hipError_t launch_scal(double a, double *x, size_t n, hipStream_t st);
 hipError_t launch_precond(double *q, const double *diag, double shift, size_t n, hipStream_t st);

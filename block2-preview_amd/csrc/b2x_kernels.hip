@@ -559,6 +559,34 @@ __global__ __launch_bounds__(256) void hpsi_generic(const b2x_pair *__restrict__
     (void)rows_per;
 }
 
+// ------------------------------------ diagonal of H_eff ------------------------------------------
+// diag[window] += alpha * a_diag (x) b_diag for every term; one workgroup column per sector (component), every
+// thread owns elements and walks the sector's terms in plan order: deterministic, no atomics (HBM/L2-bound, one-off
+// per site).
+__global__ __launch_bounds__(256) void diag_build_k(const DiagComp *__restrict__ comps, const DiagTermD *__restrict__ terms,
+                                                     const double *__restrict__ arena, double *__restrict__ diag) {
+    const DiagComp C = comps[blockIdx.x];
+    const int n = C.rows * C.cols;
+    for (int e = blockIdx.y * 256 + threadIdx.x; e < n; e += gridDim.y * 256) {
+        const int r = e / C.cols, c = e - r * C.cols;
+        double sum = 0.0;
+        for (uint32_t t = C.term_begin; t < C.term_end; t++) {
+            const DiagTermD T = terms[t];
+            const int rr = r - T.row0, cc = c - T.col0;
+            if (rr >= 0 && rr < T.m && cc >= 0 && cc < T.n)
+                sum += T.alpha * arena[T.a_off + (int64_t)rr * T.a_stride] * arena[T.b_off + (int64_t)cc * T.b_stride];
+        }
+        diag[C.base + (int64_t)r * C.ld + c] += sum;
+    }
+}
+hipError_t launch_diag(const DiagComp *comps, uint32_t n_comps, const DiagTermD *terms, const double *arena, double *diag,
+                       hipStream_t st) {
+    if (n_comps == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(diag_build_k, dim3(n_comps, 32), dim3(256), 0, st, comps, terms, arena, diag);
+    return hipGetLastError();
+}
+
 // ------------------------------------ vector kernels ------------------------------------------
 __global__ void vec_axpy_k(double a, const double *x, double *y, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

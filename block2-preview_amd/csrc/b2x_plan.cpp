@@ -523,6 +523,80 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     return B2X_OK;
 }
 
+int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,
+                 std::vector<DiagComp> &comps, std::vector<DiagTermD> &dterms, std::string &err) {
+    comps.clear(), dterms.clear();
+    std::vector<uint32_t> order(n_terms);
+    for (size_t i = 0; i < n_terms; i++) {
+        const b2x_diag_term &t = terms[i];
+        order[i] = (uint32_t)i;
+        if (t.m <= 0 || t.n <= 0 || t.ldc < t.n || t.a_stride <= 0 || t.b_stride <= 0 ||
+            t.c_off + (uint64_t)(t.m - 1) * t.ldc + t.n > diag_len ||
+            t.a_off + (uint64_t)(t.m - 1) * t.a_stride >= arena_len ||
+            t.b_off + (uint64_t)(t.n - 1) * t.b_stride >= arena_len) {
+            err = "diag term " + std::to_string(i) + ": window or operand out of range";
+            return B2X_ERR_INVALID;
+        }
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return terms[a].c_off < terms[b].c_off; });
+    size_t i = 0;
+    while (i < n_terms) {
+        const b2x_diag_term &t0 = terms[order[i]];
+        uint64_t end = t0.c_off + (uint64_t)(t0.m - 1) * t0.ldc + t0.n;
+        size_t j = i + 1;
+        while (j < n_terms && terms[order[j]].c_off < end) {
+            const b2x_diag_term &t = terms[order[j]];
+            end = std::max(end, t.c_off + (uint64_t)(t.m - 1) * t.ldc + t.n);
+            j++;
+        }
+        DiagComp c{};
+        c.base = t0.c_off, c.ld = 1, c.rows = 0, c.cols = 0;
+        for (size_t k = i; k < j; k++)
+            if (terms[order[k]].m > 1)
+                c.ld = terms[order[k]].ldc;
+        if (c.ld == 1)
+            for (size_t k = i; k < j; k++)
+                c.ld = std::max(c.ld, (int)(terms[order[k]].c_off - c.base) + terms[order[k]].n);
+        // column alignment as in compile_plan: a window must not wrap around a row
+        int c0 = 0;
+        for (size_t k = i; k < j; k++) {
+            uint64_t rel = terms[order[k]].c_off - c.base;
+            if ((int)(rel % (uint64_t)c.ld) + terms[order[k]].n > c.ld)
+                c0 = (int)((uint64_t)c.ld - rel % (uint64_t)c.ld) % c.ld;
+        }
+        if ((uint64_t)c0 > c.base) {
+            err = "diag windows do not share a row alignment";
+            return B2X_ERR_INVALID;
+        }
+        c.base -= (uint64_t)c0;
+        c.term_begin = (uint32_t)dterms.size();
+        std::vector<uint32_t> members(order.begin() + i, order.begin() + j);
+        std::sort(members.begin(), members.end()); // plan order inside the sector
+        for (uint32_t id : members) {
+            const b2x_diag_term &t = terms[id];
+            if (t.m > 1 && t.ldc != c.ld) {
+                err = "overlapping diag windows with different leading dimensions";
+                return B2X_ERR_INVALID;
+            }
+            uint64_t rel = t.c_off - c.base;
+            DiagTermD d{};
+            d.a_off = t.a_off, d.b_off = t.b_off, d.alpha = t.alpha;
+            d.row0 = (int)(rel / (uint64_t)c.ld), d.col0 = (int)(rel % (uint64_t)c.ld);
+            if (d.col0 + t.n > c.ld) {
+                err = "diag window wraps around a row";
+                return B2X_ERR_INVALID;
+            }
+            d.m = t.m, d.n = t.n, d.a_stride = t.a_stride, d.b_stride = t.b_stride;
+            c.rows = std::max(c.rows, d.row0 + d.m), c.cols = std::max(c.cols, d.col0 + d.n);
+            dterms.push_back(d);
+        }
+        c.term_end = (uint32_t)dterms.size();
+        comps.push_back(c);
+        i = j;
+    }
+    return B2X_OK;
+}
+
 void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double *psi, double *sigma, double scale) {
     std::vector<double> slabs(cp.slab_elems, 0.0);
     for (int k = 0; k < kNumClasses; k++) {

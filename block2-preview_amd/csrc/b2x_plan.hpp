@@ -112,6 +112,22 @@ struct CompiledPlan {
     std::string fallback_reason;
 };
 
+// ---- diagonal build ----------------------------------------------------------------------------------------
+struct DiagTermD {
+    uint64_t a_off, b_off;
+    double alpha;
+    int32_t row0, col0, m, n; // window inside the component
+    int32_t a_stride, b_stride;
+};
+struct DiagComp {
+    uint64_t base; // diag offset of the component's (0, 0)
+    int32_t ld, rows, cols;
+    uint32_t term_begin, term_end;
+};
+// groups the terms by output sector (overlapping windows), keeping plan order inside a sector
+int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,
+                 std::vector<DiagComp> &comps, std::vector<DiagTermD> &dterms, std::string &err);
+
 // returns 0 / B2X_ERR_INVALID (err filled)
 int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len, uint64_t arena_len,
                  const b2x_plan_options *opt, CompiledPlan &out, std::string &err);

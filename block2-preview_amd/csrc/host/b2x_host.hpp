@@ -125,6 +125,71 @@ struct BatchGEMMSeq {
                  scale, bra.data, bra.n, c.data + cst, c.n);
         }
     }
+    // ---- diagonal of H_eff: rank-1 products of operator-block diagonals -------------------------------------
+    // c[i][j] += scale * a[i][i] * b[j][j]     (AdvancedGEMM::tensor_product_diagonal, batch_gemm.hpp:507-524)
+    std::vector<b2x_diag_term> diag_terms;
+    std::vector<const double *> da_ptr, db_ptr;
+    void push_diag(const double *a, int a_stride, int m, const double *b, int b_stride, int n, double *c, int ldc,
+                   double alpha) {
+        b2x_diag_term t{};
+        t.m = m, t.n = n, t.a_stride = a_stride, t.b_stride = b_stride, t.ldc = ldc, t.alpha = alpha;
+        t.c_off = (uint64_t)(c - (double *)0);
+        diag_terms.push_back(t);
+        da_ptr.push_back(a), db_ptr.push_back(b);
+    }
+    void tensor_product_diagonal(uint8_t /*conj*/, const GMatrix &a, const GMatrix &b, const GMatrix &c, double scale) {
+        if (a.m != a.n || b.m != b.n || c.m != a.n || c.n != b.n)
+            throw std::runtime_error("tensor_product_diagonal: shape mismatch");
+        push_diag(a.data, a.n + 1, a.n, b.data, b.n + 1, b.n, c.data, c.n, scale);
+    }
+    // diagonal of (da x db) x b  or  a x (da x db), one of da / db being 1 x 1 (matrix_functions.hpp:1189-1240):
+    // only a diagonal sub-block (row offset == column offset of `stride`) contributes
+    void three_tensor_product_diagonal(uint8_t /*conj*/, const GMatrix &a, const GMatrix &b, const GMatrix &c,
+                                       const GMatrix &da, bool /*dconja*/, const GMatrix &db, bool /*dconjb*/, bool dleft,
+                                       double scale, uint64_t stride) {
+        const int dstrm = (int)(stride / (uint64_t)(dleft ? a.m : b.m)), dstrn = (int)(stride % (uint64_t)(dleft ? a.m : b.m));
+        if (dstrn != dstrm)
+            return;
+        const bool a_scalar = da.m == 1 && da.n == 1;
+        if (!a_scalar && !(db.m == 1 && db.n == 1))
+            throw std::runtime_error("three_tensor_product_diagonal: one factor must be 1 x 1");
+        const GMatrix &big = a_scalar ? db : da;
+        const double sc = scale * (a_scalar ? *da.data : *db.data);
+        if (dleft) // rows [dstr, dstr + big.n) of c
+            push_diag(big.data, big.n + 1, big.n, b.data, b.n + 1, b.n, c.data + (size_t)dstrn * c.n, c.n, sc);
+        else // columns [dstr, dstr + big.n) of c
+            push_diag(a.data, a.n + 1, a.n, big.data, big.n + 1, big.n, c.data + dstrn, c.n, sc);
+    }
+    // execute the recorded diagonal terms: diag (host vector) += terms
+    void diag_perform(double *diag, size_t len) {
+        if (diag_terms.empty())
+            return;
+        std::vector<std::pair<const double *, size_t>> ext;
+        for (size_t i = 0; i < diag_terms.size(); i++) {
+            ext.emplace_back(da_ptr[i], (size_t)(diag_terms[i].m - 1) * diag_terms[i].a_stride + 1);
+            ext.emplace_back(db_ptr[i], (size_t)(diag_terms[i].n - 1) * diag_terms[i].b_stride + 1);
+        }
+        std::sort(ext.begin(), ext.end());
+        std::vector<const double *> bases;
+        std::vector<size_t> lens;
+        for (auto &e : ext) {
+            if (!bases.empty() && e.first <= bases.back() + lens.back())
+                lens.back() = std::max(lens.back(), (size_t)(e.first - bases.back()) + e.second);
+            else
+                bases.push_back(e.first), lens.push_back(e.second);
+        }
+        b2x_arena *ar = nullptr;
+        check(b2x_arena_create(&ar, bases.size(), bases.data(), lens.data()));
+        std::vector<b2x_diag_term> terms = diag_terms;
+        for (size_t i = 0; i < terms.size(); i++) {
+            check(b2x_arena_resolve(ar, da_ptr[i], &terms[i].a_off));
+            check(b2x_arena_resolve(ar, db_ptr[i], &terms[i].b_off));
+        }
+        int rc = b2x_diag_build(ar, terms.size(), terms.data(), len, diag, 0, nullptr);
+        b2x_arena_destroy(ar);
+        check(rc);
+        diag_terms.clear(), da_ptr.clear(), db_ptr.clear();
+    }
     // upload the operator ranges + compile the device plan (lazily, on first execution)
     void prepare(size_t psi_len_, size_t sigma_len_) {
         if (plan != nullptr)

@@ -241,6 +241,64 @@ template <typename S> struct SparseMatrixInfo {
                     n[i] = n[i + 1];
             nc = (int)stride.size();
         }
+        // connections of the DIAGONAL of H_eff: (ia, ib, ic) with a[ia], b[ib] diagonal blocks of psi sector ic
+        // (sparse_matrix.hpp:80-159); sub-labels whose operators cannot be diagonal get an empty range
+        void initialize_diag(S cdq, S opdq, const std::vector<std::pair<uint8_t, S>> &subdq,
+                             const std::vector<std::pair<S, std::shared_ptr<SparseMatrixInfo>>> &ainfos,
+                             const std::vector<std::pair<S, std::shared_ptr<SparseMatrixInfo>>> &binfos,
+                             const std::shared_ptr<SparseMatrixInfo> &cinfo, const CG<S> &cg) {
+            quanta.clear(), idx.clear(), stride.clear(), factor.clear(), ia.clear(), ib.clear(), ic.clear();
+            if (ainfos.empty() || binfos.empty()) {
+                n[4] = nc = 0;
+                return;
+            }
+            for (int i = 0; i < 5; i++)
+                n[i] = -1;
+            auto find_info = [](const std::vector<std::pair<S, std::shared_ptr<SparseMatrixInfo>>> &infos, S q) {
+                auto it = std::lower_bound(infos.begin(), infos.end(), q,
+                                           [](const std::pair<S, std::shared_ptr<SparseMatrixInfo>> &p, S x) {
+                                               return p.first < x;
+                                           });
+                if (it == infos.end() || it->first != q)
+                    throw std::runtime_error("initialize_diag: operator delta quantum without an info");
+                return it->second;
+            };
+            for (size_t k = 0; k < subdq.size(); k++) {
+                const uint8_t cj = subdq[k].first;
+                if (n[cj] == -1)
+                    n[cj] = (int)k;
+                const bool cja = cj & 1, cjb = (cj & 2) >> 1;
+                idx.push_back((uint32_t)ic.size());
+                quanta.push_back(subdq[k].second);
+                S adq = cja ? -subdq[k].second.get_bra(opdq) : subdq[k].second.get_bra(opdq);
+                S bdq = cjb ? subdq[k].second.get_ket() : -subdq[k].second.get_ket();
+                if ((adq + bdq)[0] != (adq - adq)[0]) // the pair of operators changes the quantum numbers
+                    continue;
+                auto ainfo = find_info(ainfos, adq), binfo = find_info(binfos, bdq);
+                for (int jc = 0; jc < cinfo->n; jc++) {
+                    S aq = cinfo->quanta[jc].get_bra(cdq), bq = -cinfo->quanta[jc].get_ket();
+                    int ja = ainfo->find_state(aq), jb = binfo->find_state(bq);
+                    if (ja == -1 || jb == -1 || aq != aq.get_bra(adq) || bq != bq.get_bra(bdq))
+                        continue;
+                    double f = std::sqrt((double)cdq.multiplicity() * opdq.multiplicity() * aq.multiplicity() *
+                                         bq.multiplicity()) *
+                               cg.wigner_9j(aq, bq, cdq, adq, bdq, opdq, aq, bq, cdq);
+                    if (cja)
+                        f *= cg.transpose_cg(adq, aq, aq);
+                    if (cjb)
+                        f *= cg.transpose_cg(bdq, bq, bq);
+                    f *= (binfo->is_fermion && aq.is_fermion()) ? -1 : 1;
+                    if (std::fabs(f) >= 1E-20)
+                        ia.push_back((uint32_t)ja), ib.push_back((uint32_t)jb), ic.push_back((uint32_t)jc),
+                            factor.push_back(f), stride.push_back(0);
+                }
+            }
+            n[4] = (int)subdq.size();
+            for (int i = 3; i >= 0; i--)
+                if (n[i] == -1)
+                    n[i] = n[i + 1];
+            nc = (int)ic.size();
+        }
     };
     std::vector<S> quanta; // sorted ascending by packed value
     std::vector<uint32_t> n_states_bra, n_states_ket, n_states_total;
@@ -314,6 +372,59 @@ template <typename S> struct OperatorFunctions {
             seq->rotate(c[(int)ci.ic[il]], v[(int)ci.stride[il]], a[(int)ci.ia[il]], (conj & 1) ? 3 : 0,
                         b[(int)ci.ib[il]], (conj & 2) ? 2 : 1, scale * ci.factor[il]);
     }
+    // diag(c)[ic] += scale * factor * diag(a[ia]) (x) diag(b[ib])       (operator_functions.hpp:211-245)
+    void tensor_product_diagonal(uint8_t conj, const SparseMatrix<S> &a, const SparseMatrix<S> &b,
+                                 const SparseMatrix<S> &c, S opdq, double scale = 1.0) const {
+        scale = scale * a.factor * b.factor;
+        if (std::fabs(scale) < 1E-20)
+            return;
+        S adq = a.info->delta_quantum, bdq = b.info->delta_quantum;
+        const auto &ci = *c.info->cinfo;
+        S abdq = opdq.combine((conj & 1) ? -adq : adq, (conj & 2) ? bdq : -bdq);
+        int ik = (int)(std::lower_bound(ci.quanta.begin() + ci.n[conj], ci.quanta.begin() + ci.n[conj + 1], abdq) -
+                       ci.quanta.begin());
+        if (ik >= ci.n[conj + 1] || ci.quanta[ik] != abdq)
+            throw std::runtime_error("tensor_product_diagonal: sub-label not in the connection info");
+        int ixa = (int)ci.idx[ik], ixb = ik == ci.n[4] - 1 ? ci.nc : (int)ci.idx[ik + 1];
+        for (int il = ixa; il < ixb; il++)
+            seq->tensor_product_diagonal(conj, a[(int)ci.ia[il]], b[(int)ci.ib[il]], c[(int)ci.ic[il]],
+                                         scale * ci.factor[il]);
+    }
+    // the delayed variant (operator_functions.hpp:246-328)
+    void three_tensor_product_diagonal(uint8_t conj, const SparseMatrix<S> &a, const SparseMatrix<S> &b,
+                                       const SparseMatrix<S> &c, uint8_t dconj, const SparseMatrix<S> &da,
+                                       const SparseMatrix<S> &db, bool dleft, S opdq, double scale = 1.0) const {
+        scale = scale * a.factor * b.factor * da.factor * db.factor;
+        if (std::fabs(scale) < 1E-20)
+            return;
+        const SparseMatrix<S> &dc = dleft ? a : b;
+        S adq = a.info->delta_quantum, bdq = b.info->delta_quantum;
+        S abdq = opdq.combine((conj & 1) ? -adq : adq, (conj & 2) ? bdq : -bdq);
+        S dadq = da.info->delta_quantum, dbdq = db.info->delta_quantum, dcdq = dc.info->delta_quantum;
+        S dabdq = dcdq.combine((dconj & 1) ? -dadq : dadq, (dconj & 2) ? dbdq : -dbdq);
+        if (!c.info->cinfo || !dc.info->cinfo)
+            throw std::runtime_error("three_tensor_product_diagonal: missing connection info");
+        const auto &ci = *c.info->cinfo, &di = *dc.info->cinfo;
+        int ik = (int)(std::lower_bound(ci.quanta.begin() + ci.n[conj], ci.quanta.begin() + ci.n[conj + 1], abdq) -
+                       ci.quanta.begin());
+        if (ik >= ci.n[conj + 1] || ci.quanta[ik] != abdq)
+            throw std::runtime_error("three_tensor_product_diagonal: sub-label not in the connection info");
+        int ixa = (int)ci.idx[ik], ixb = ik == ci.n[4] - 1 ? ci.nc : (int)ci.idx[ik + 1];
+        int idk = (int)(std::lower_bound(di.quanta.begin() + di.n[dconj], di.quanta.begin() + di.n[dconj + 1], dabdq) -
+                        di.quanta.begin());
+        if (idk >= di.n[dconj + 1] || di.quanta[idk] != dabdq)
+            throw std::runtime_error("three_tensor_product_diagonal: delayed sub-label not in its connection info");
+        int idxa = (int)di.idx[idk], idxb = idk == di.n[4] - 1 ? di.nc : (int)di.idx[idk + 1];
+        for (int il = ixa; il < ixb; il++) {
+            int ja = (int)ci.ia[il], jb = (int)ci.ib[il], jc = (int)ci.ic[il];
+            uint32_t idc = (uint32_t)(dleft ? ja : jb);
+            int idl = (int)(std::lower_bound(di.ic.begin() + idxa, di.ic.begin() + idxb, idc) - di.ic.begin());
+            for (; idl < idxb && di.ic[idl] == idc; idl++)
+                seq->three_tensor_product_diagonal(conj, a[ja], b[jb], c[jc], da[(int)di.ia[idl]], dconj & 1,
+                                                   db[(int)di.ib[idl]], (dconj & 2) >> 1, dleft,
+                                                   scale * ci.factor[il] * di.factor[idl], di.stride[idl]);
+        }
+    }
     // same with the left (dleft) or right operator still delayed as da (x) db: nested connection lists
     void three_tensor_product_multiply(uint8_t conj, const SparseMatrix<S> &a, const SparseMatrix<S> &b,
                                        const SparseMatrix<S> &c, const SparseMatrix<S> &v, uint8_t dconj,
@@ -375,6 +486,20 @@ template <typename S> struct TensorFunctions {
                 opf->tensor_product_multiply(t.conj, *lopt.ops[t.a], *ropt.ops[t.b], cmat, vmat, opdq, t.factor);
         }
     }
+    // diag(mat) += diagonal of expr   (tensor_functions.hpp:2027-2182)
+    void tensor_product_diagonal(const std::vector<OpTerm> &expr, const OperatorTensor<S> &lopt,
+                                 const OperatorTensor<S> &ropt, const SparseMatrix<S> &mat, S opdq) const {
+        for (const OpTerm &t : expr) {
+            if (t.type == OpTypes::SumProd) {
+                const bool dleft = lopt.get_type() == OperatorTensorTypes::Delayed;
+                const OperatorTensor<S> &dopt = dleft ? lopt : ropt;
+                opf->three_tensor_product_diagonal(t.conj, *lopt.ops[t.a], *ropt.ops[t.b], mat, t.dconj,
+                                                   *dopt.lopt->ops[t.d0], *dopt.ropt->ops[t.d1], dleft, opdq,
+                                                   t.factor);
+            } else
+                opf->tensor_product_diagonal(t.conj, *lopt.ops[t.a], *ropt.ops[t.b], mat, opdq, t.factor);
+        }
+    }
     // c += scale * H b : replay of the recorded plan (tensor_functions.hpp:59-62)
     void operator()(const GMatrix &b, const GMatrix &c, double scale = 1.0) { (*opf->seq)(b, c, scale); }
 };
@@ -388,6 +513,7 @@ template <typename S> struct SymbolicEffectiveHamiltonian {
     std::vector<OpTerm> expr;
     std::shared_ptr<Info> ket_info, bra_info;
     S opdq;
+    std::vector<std::pair<uint8_t, S>> subdq;
     std::shared_ptr<typename Info::ConnectionInfo> wfn_info;
     std::shared_ptr<TensorFunctions<S>> tf;
     std::vector<double> diag;
@@ -398,13 +524,27 @@ template <typename S> struct SymbolicEffectiveHamiltonian {
                                  const std::shared_ptr<Info> &ket_info, const std::shared_ptr<Info> &bra_info, S opdq,
                                  const std::vector<std::pair<uint8_t, S>> &subdq, const std::vector<double> &diag)
         : left_op_infos(linfos), right_op_infos(rinfos), lopt(lopt), ropt(ropt), expr(expr), ket_info(ket_info),
-          bra_info(bra_info), opdq(opdq), diag(diag) {
+          bra_info(bra_info), opdq(opdq), subdq(subdq), diag(diag) {
         auto seq = std::make_shared<BatchGEMMSeq>();
         tf = std::make_shared<TensorFunctions<S>>(std::make_shared<OperatorFunctions<S>>(seq));
         wfn_info = std::make_shared<typename Info::ConnectionInfo>();
         wfn_info->initialize_wfn(ket_info->delta_quantum, bra_info->delta_quantum, opdq, subdq, left_op_infos,
                                  right_op_infos, ket_info, bra_info, tf->opf->cg);
         ket_info->cinfo = wfn_info;
+    }
+    // diagonal of H_eff as the reference's constructor builds it (effective_hamiltonian.hpp:189-200):
+    // initialize_diag + tensor_product_diagonal, evaluated on the device
+    std::vector<double> compute_diag(const std::vector<std::pair<uint8_t, S>> &subdq) {
+        auto dinfo = std::make_shared<Info>(*ket_info);
+        dinfo->cinfo = std::make_shared<typename Info::ConnectionInfo>();
+        dinfo->cinfo->initialize_diag(ket_info->delta_quantum, opdq, subdq, left_op_infos, right_op_infos, dinfo,
+                                      tf->opf->cg);
+        SparseMatrix<S> dmat;
+        dmat.info = dinfo, dmat.data = (double *)0, dmat.factor = 1.0;
+        tf->tensor_product_diagonal(expr, *lopt, *ropt, dmat, opdq);
+        std::vector<double> d(ket_info->get_total_memory(), 0.0);
+        tf->opf->seq->diag_perform(d.data(), d.size());
+        return d;
     }
     // record the plan with null-based wavefunctions (every psi / psi' address becomes an element offset)
     void precompute() {

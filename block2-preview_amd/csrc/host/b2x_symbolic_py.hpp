@@ -20,6 +20,8 @@ struct SymEHBase {
     virtual size_t nflop() const = 0;
     virtual py::array pairs() const = 0;
     virtual void record() = 0;
+    virtual py::array_t<double> compute_diag() = 0;
+    virtual py::array diag_terms() = 0;
     virtual void apply(py::array_t<double, py::array::c_style> b, py::array_t<double, py::array::c_style> c,
                        double factor) = 0;
     virtual py::tuple eigs(std::vector<double> ket, double conv_thrd, int max_iter) = 0;
@@ -161,6 +163,32 @@ template <typename S> struct SymEH : SymEHBase {
         r["ia"] = c.ia, r["ib"] = c.ib, r["ic"] = c.ic;
         return r;
     }
+    py::array_t<double> compute_diag() override {
+        std::vector<double> d = h->compute_diag(h->subdq);
+        return py::array_t<double>(d.size(), d.data());
+    }
+    // record the diagonal terms only (initialize_diag + tensor_product_diagonal), offsets relative to the arena
+    py::array diag_terms() override {
+        typedef SparseMatrixInfo<S> I;
+        auto dinfo = std::make_shared<I>(*h->ket_info);
+        dinfo->cinfo = std::make_shared<typename I::ConnectionInfo>();
+        dinfo->cinfo->initialize_diag(h->ket_info->delta_quantum, h->opdq, h->subdq, h->left_op_infos,
+                                      h->right_op_infos, dinfo, h->tf->opf->cg);
+        SparseMatrix<S> dmat;
+        dmat.info = dinfo, dmat.data = (double *)0, dmat.factor = 1.0;
+        auto &sq = *h->tf->opf->seq;
+        sq.diag_terms.clear(), sq.da_ptr.clear(), sq.db_ptr.clear();
+        h->tf->tensor_product_diagonal(h->expr, *h->lopt, *h->ropt, dmat, h->opdq);
+        std::vector<b2x_diag_term> t = sq.diag_terms;
+        for (size_t i = 0; i < t.size(); i++) {
+            t[i].a_off = (uint64_t)(sq.da_ptr[i] - arena.data());
+            t[i].b_off = (uint64_t)(sq.db_ptr[i] - arena.data());
+        }
+        sq.diag_terms.clear(), sq.da_ptr.clear(), sq.db_ptr.clear();
+        py::array_t<uint8_t> a(t.size() * sizeof(b2x_diag_term));
+        std::memcpy(a.mutable_data(), t.data(), t.size() * sizeof(b2x_diag_term));
+        return a;
+    }
     void precompute() override { h->precompute(); }
     void post_precompute() override { h->post_precompute(); }
     size_t n_pairs() const override { return h->tf->opf->seq->pairs.size(); }
@@ -214,6 +242,8 @@ inline void bind_symbolic(py::module_ &m) {
         .def_property_readonly("nflop", &SymEHBase::nflop)
         .def("pairs", &SymEHBase::pairs)
         .def("record", &SymEHBase::record)
+        .def("compute_diag", &SymEHBase::compute_diag)
+        .def("diag_terms", &SymEHBase::diag_terms)
         .def("__call__", &SymEHBase::apply, py::arg("b"), py::arg("c"), py::arg("factor") = 1.0)
         .def("eigs", &SymEHBase::eigs, py::arg("ket"), py::arg("conv_thrd") = 5E-6, py::arg("max_iter") = 5000);
     // label algebra exposed for unit tests (packed 64-bit in / out)

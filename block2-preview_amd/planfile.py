@@ -17,6 +17,11 @@ PAIR_DTYPE = np.dtype(
 )
 assert PAIR_DTYPE.itemsize == 96
 
+# numpy view of b2x_diag_term (include/b2x.h)
+DIAG_TERM_DTYPE = np.dtype([("m", "<i4"), ("n", "<i4"), ("a_stride", "<i4"), ("b_stride", "<i4"), ("ldc", "<i4"),
+                            ("reserved", "<i4"), ("alpha", "<f8"), ("a_off", "<u8"), ("b_off", "<u8"), ("c_off", "<u8")])
+assert DIAG_TERM_DTYPE.itemsize == 56
+
 F_ARENA, F_PSI, F_SIGMA, F_DIAG, F_PSIOUT = 1, 2, 4, 8, 16
 
 

@@ -129,6 +129,24 @@ int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, 
                          double *avg_ms_main, double *avg_ms_total);
 int b2x_plan_destroy(b2x_plan *p);
 
+/* diagonal of H_eff (Olsen preconditioner of Davidson) --------------------------------------------------
+ * Replaces: the rank-1 products recorded by BatchGEMMSeq / AdvancedGEMM::tensor_product_diagonal and
+ * three_tensor_product_diagonal (src/core/batch_gemm.hpp:507-563, src/core/matrix_functions.hpp:1179-1240),
+ * driven by OperatorFunctions::tensor_product_diagonal (src/core/operator_functions.hpp:211-328).
+ * One term:  C[r][c] += alpha * A[a_off + r*a_stride] * B[b_off + c*b_stride],  r < m, c < n, where C is a window
+ * (c_off, ldc) of the diagonal vector and A / B walk the diagonals of two operator blocks (stride = ld + 1). */
+typedef struct b2x_diag_term {
+    int32_t m, n;
+    int32_t a_stride, b_stride;
+    int32_t ldc, reserved;
+    double alpha;
+    uint64_t a_off, b_off; /* arena element offsets */
+    uint64_t c_off;        /* element offset into the diagonal vector */
+} b2x_diag_term;
+/* diag += sum of terms.  on_device != 0: diag is a device pointer.  Deterministic (no atomics). */
+int b2x_diag_build(const b2x_arena *arena, size_t n_terms, const b2x_diag_term *terms, size_t diag_len, double *diag,
+                   int on_device, void *stream);
+
 /* device-resident vector algebra for Davidson (all pointers are device pointers) ------------ */
 int b2x_vec_dot(const double *x, const double *y, size_t n, double *host_result, void *stream);
 int b2x_vec_axpy(double a, const double *x, double *y, size_t n, void *stream);   /* y += a x */

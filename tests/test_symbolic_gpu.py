@@ -44,3 +44,14 @@ def test_symbolic_eigs_site_energy(host):
     # N2/STO-3G: the sweep-1 site energy of the generating run is the converged ground state
     assert abs(e + float(d["const_e"][0]) - (-107.654122447525)) < 1e-6
     assert nflop == ndav * int(d["n_pairs"][1])
+
+
+@pytest.mark.parametrize("fn", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_diag_build_on_device(host, fn):
+    """diag of H_eff built on the device (b2x_diag_build) == the reference's diag (EffectiveHamiltonian ctor)"""
+    d = read_arrays(fn)
+    h = host.SymbolicEffectiveHamiltonian("su2" if "su2" in os.path.basename(fn) else "sz", d)
+    diag = np.asarray(h.compute_diag())
+    assert np.abs(diag - d["diag"]).max() <= 1e-12 * max(1.0, np.abs(d["diag"]).max())
+    again = np.asarray(h.compute_diag())
+    assert np.array_equal(diag, again)  # deterministic

@@ -89,3 +89,23 @@ def test_wigner_symbols(host):
     lhs = host.wigner_9j(a, b, c, dd, e, c, g, g, 0)
     rhs = (-1) ** ((b + c + dd + g) // 2) / np.sqrt((c + 1) * (g + 1)) * host.wigner_6j(a, b, c, e, dd, g)
     assert abs(lhs - rhs) < 1e-14
+
+
+@pytest.mark.parametrize("fn", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_diagonal_terms_match_reference_diag(host, fn):
+    """§8f row 1: ConnectionInfo::initialize_diag (sparse_matrix.hpp:80-159) + (three_)tensor_product_diagonal
+    (operator_functions.hpp:211-328) record rank-1 terms whose sum is the reference's diag (evaluated here with numpy,
+    on the device in test_symbolic_gpu.py)."""
+    from block2_preview_amd.planfile import DIAG_TERM_DTYPE
+
+    d = read_arrays(fn)
+    h = host.SymbolicEffectiveHamiltonian(sym_of(fn), d)
+    t = np.frombuffer(h.diag_terms().tobytes(), DIAG_TERM_DTYPE)
+    assert len(t) > 0
+    diag, ar = np.zeros(len(d["diag"])), d["arena"]
+    for x in t:
+        a = ar[int(x["a_off"]):int(x["a_off"]) + (x["m"] - 1) * x["a_stride"] + 1:x["a_stride"]]
+        b = ar[int(x["b_off"]):int(x["b_off"]) + (x["n"] - 1) * x["b_stride"] + 1:x["b_stride"]]
+        idx = int(x["c_off"]) + np.arange(x["m"])[:, None] * x["ldc"] + np.arange(x["n"])[None, :]
+        diag[idx] += x["alpha"] * np.outer(a, b)
+    assert np.abs(diag - d["diag"]).max() <= 1e-12 * max(1.0, np.abs(d["diag"]).max())
