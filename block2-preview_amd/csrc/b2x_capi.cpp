@@ -508,6 +508,20 @@ int b2x_vec_lincomb(const double *const *vs, int nv, const double *coef, double 
     return B2X_OK;
 }
 
+// test hook: segmentation of diagonal terms only (no device)
+int b2x_debug_compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,
+                           uint64_t *n_comps) {
+    std::vector<DiagComp> comps;
+    std::vector<DiagTermD> dterms;
+    std::string err;
+    int rc = compile_diag(n_terms, terms, diag_len, arena_len, comps, dterms, err);
+    if (rc != B2X_OK)
+        return fail(rc, err);
+    if (n_comps)
+        *n_comps = comps.size();
+    return B2X_OK;
+}
+
 // ---------------------------------------------------------------------------------- test hook
 // Compiles a plan and evaluates the compiled work list with plain host loops.  Exists so the
 // non-GPU test-suite can verify the PLAN COMPILER (segmentation into tiles/parts/items) against

@@ -550,13 +550,15 @@ int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, ui
             j++;
         }
         DiagComp c{};
-        c.base = t0.c_off, c.ld = 1, c.rows = 0, c.cols = 0;
+        c.base = t0.c_off, c.ld = 0, c.rows = 0, c.cols = 0;
         for (size_t k = i; k < j; k++)
             if (terms[order[k]].m > 1)
-                c.ld = terms[order[k]].ldc;
-        if (c.ld == 1)
+                c.ld = terms[order[k]].ldc; // (a one-column sector legitimately has ld == 1)
+        if (c.ld == 0) { // only single-row windows: any ld that holds them all
+            c.ld = 1;
             for (size_t k = i; k < j; k++)
                 c.ld = std::max(c.ld, (int)(terms[order[k]].c_off - c.base) + terms[order[k]].n);
+        }
         // column alignment as in compile_plan: a window must not wrap around a row
         int c0 = 0;
         for (size_t k = i; k < j; k++) {

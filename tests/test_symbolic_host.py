@@ -109,3 +109,21 @@ def test_diagonal_terms_match_reference_diag(host, fn):
         idx = int(x["c_off"]) + np.arange(x["m"])[:, None] * x["ldc"] + np.arange(x["n"])[None, :]
         diag[idx] += x["alpha"] * np.outer(a, b)
     assert np.abs(diag - d["diag"]).max() <= 1e-12 * max(1.0, np.abs(d["diag"]).max())
+
+
+@pytest.mark.parametrize("fn", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_diag_terms_segment_without_device(host, fn):
+    """the device-side grouping of diagonal terms by psi sector accepts every fixture (incl. one-column sectors)"""
+    import ctypes as C
+
+    from block2_preview_amd import capi
+    from block2_preview_amd.planfile import DIAG_TERM_DTYPE
+
+    d = read_arrays(fn)
+    h = host.SymbolicEffectiveHamiltonian(sym_of(fn), d)
+    t = np.frombuffer(h.diag_terms().tobytes(), DIAG_TERM_DTYPE).copy()
+    n = C.c_uint64()
+    capi.check(capi.lib().b2x_debug_compile_diag(C.c_size_t(len(t)), t.ctypes.data_as(C.c_void_p),
+                                                 C.c_size_t(len(d["diag"])), C.c_uint64(len(d["arena"])), C.byref(n)))
+    k = int(d["ket.info"][0])
+    assert n.value <= len(d["info.%d.quanta" % k])  # at most one component per psi sector
