@@ -300,19 +300,16 @@ __global__ __launch_bounds__(256, (TMF <= 2 ? 4 : (TMF <= 4 ? 3 : 2))) void hpsi
 // row-slice boundaries of the sector, so a segment's rows always cover its tile: only columns (B side)
 // and the k tail need masking, and both are applied to the B registers.
 template <int TMF, int CF, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
-                                                         const double *__restrict__ arena,
-                                                         const double *__restrict__ psi, double *__restrict__ scratch,
-                                                         double *__restrict__ slabs) {
+__device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GSeg *__restrict__ segs,
+                                        const double *__restrict__ arena, const double *__restrict__ psi,
+                                        double *__restrict__ scratch, double *__restrict__ slabs) {
     constexpr int TM = TMF * 16, NT = NW * 64;
     constexpr int ABUF = TM * 16;        // doubles per LDS buffer (unpadded: the DMA image is lane-linear)
     constexpr int NG = TM * 8;           // 16-byte granules per chunk
     constexpr int NI = (NG + NT - 1) / NT; // DMA instructions per thread per chunk
-    __shared__ __attribute__((aligned(16))) double lds[2 * ABUF];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const GItem item = items[blockIdx.x];
 
     v4d acc[TMF][CF];
 #pragma unroll
@@ -496,6 +493,26 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__
                 }
         }
     }
+}
+
+// One launch per stage: every workgroup picks the body specialised for its item's tile height (64-row units), so
+// tiles of all heights share a grid (no per-variant launch tails) and one LDS allocation.
+template <int CF, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
+                                                         const double *__restrict__ arena,
+                                                         const double *__restrict__ psi, double *__restrict__ scratch,
+                                                         double *__restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) double lds[2 * 256 * 16];
+    const GItem item = items[blockIdx.x];
+    const int v = (item.rows - 1) >> 6;
+    if (v == 0)
+        gg_body<4, CF, NW>(item, lds, segs, arena, psi, scratch, slabs);
+    else if (v == 1)
+        gg_body<8, CF, NW>(item, lds, segs, arena, psi, scratch, slabs);
+    else if (v == 2)
+        gg_body<12, CF, NW>(item, lds, segs, arena, psi, scratch, slabs);
+    else
+        gg_body<16, CF, NW>(item, lds, segs, arena, psi, scratch, slabs);
 }
 
 // psi'[tile] += scale * sum_i slab_i[tile]   (fixed order i = 0..n_items-1)
@@ -687,37 +704,14 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
     return hipErrorInvalidValue;
 }
 
-template <int TMF>
-static void launch_gg_t(const GSeg *segs, const GItem *items, uint32_t n, const double *arena, const double *psi,
-                        double *scratch, double *slabs, hipStream_t st) {
-    // 8 waves x (TMF row fragments x 1 column fragment): <= 128 accumulator VGPRs per wave, 2 waves per SIMD
-    hipLaunchKernelGGL((gg_kernel<TMF, 1, kGGTileN / 16>), dim3(n), dim3(kGGTileN * 4), 0, st, segs, items, arena, psi,
-                       scratch, slabs);
-}
-
-// items are grouped by tile-height variant: v_begin[v] .. v_begin[v+1] use gg_kernel<4*(v+1)>
+// items of all tile-height variants in one grid: v_begin[0] .. v_begin[kGGVariants]
 hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_begin, const double *arena,
                      const double *psi, double *scratch, double *slabs, hipStream_t st) {
-    for (int v = 0; v < kGGVariants; v++) {
-        uint32_t n = v_begin[v + 1] - v_begin[v];
-        if (n == 0)
-            continue;
-        const GItem *it = items + v_begin[v];
-        switch (v) {
-        case 0:
-            launch_gg_t<4>(segs, it, n, arena, psi, scratch, slabs, st);
-            break;
-        case 1:
-            launch_gg_t<8>(segs, it, n, arena, psi, scratch, slabs, st);
-            break;
-        case 2:
-            launch_gg_t<12>(segs, it, n, arena, psi, scratch, slabs, st);
-            break;
-        default:
-            launch_gg_t<16>(segs, it, n, arena, psi, scratch, slabs, st);
-            break;
-        }
-    }
+    const uint32_t n = v_begin[kGGVariants] - v_begin[0];
+    if (n == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL((gg_kernel<1, kGGTileN / 16>), dim3(n), dim3(kGGTileN * 4), 0, st, segs, items + v_begin[0],
+                       arena, psi, scratch, slabs);
     return hipGetLastError();
 }
 

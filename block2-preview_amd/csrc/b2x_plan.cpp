@@ -457,21 +457,19 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             ss.tile_end = (uint32_t)out.gtiles.size();
             // group by tile-height variant; inside a variant, longest items first
             auto variant = [](const GItem &x) { return std::min(kGGVariants - 1, (x.rows - 1) / 64); };
-            auto order = [&](const GItem &x, const GItem &y) {
-                int vx = variant(x), vy = variant(y);
-                if (vx != vy)
-                    return vx < vy;
-                return (x.seg_end - x.seg_begin) > (y.seg_end - y.seg_begin);
+            // one grid per stage holds the items of all tile heights: longest (by MFMA issue slots) first
+            auto icost = [&](const GItem &x) {
+                uint64_t k = 0;
+                for (uint32_t q = x.seg_begin; q < x.seg_end; q++)
+                    k += (uint64_t)round_up(out.gsegs[q].K, 16);
+                return k * (uint64_t)(variant(x) + 1);
             };
+            auto order = [&](const GItem &x, const GItem &y) { return icost(x) > icost(y); };
             std::stable_sort(out.gitems.begin() + s0_begin, out.gitems.begin() + s1_begin, order);
             std::stable_sort(out.gitems.begin() + s1_begin, out.gitems.begin() + s1_end, order);
-            auto fill = [&](uint32_t b, uint32_t e, uint32_t *v) {
-                uint32_t pos = b;
-                for (int k = 0; k < kGGVariants; k++) {
-                    v[k] = pos;
-                    while (pos < e && variant(out.gitems[pos]) == k)
-                        pos++;
-                }
+            auto fill = [&](uint32_t b, uint32_t e, uint32_t *v) { // variants share one launch: [v[0], v[last])
+                for (int k = 0; k < kGGVariants; k++)
+                    v[k] = b;
                 v[kGGVariants] = e;
             };
             fill(s0_begin, s1_begin, ss.s0_v);
@@ -515,8 +513,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         st.dominant_class = kNumClasses, st.macs_dominant = gg_macs, st.macs_alg_dominant = gg_macs;
         st.n_launches = 0;
         for (const SuperStep &ss : out.steps)
-            for (int v = 0; v < kGGVariants; v++)
-                st.n_launches += (ss.s0_v[v + 1] > ss.s0_v[v]) + (ss.s1_v[v + 1] > ss.s1_v[v]);
+            st.n_launches += (ss.s0_v[kGGVariants] > ss.s0_v[0]) + (ss.s1_v[kGGVariants] > ss.s1_v[0]);
     }
     st.device_bytes = (out.scratch_elems + out.gslab_elems) * 8 + out.gsegs.size() * sizeof(GSeg) +
                       out.gitems.size() * sizeof(GItem) + out.gtiles.size() * sizeof(DTile) + slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
