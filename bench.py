@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tile-n", type=int, default=0)
     ap.add_argument("--item-macs", type=int, default=0)
+    ap.add_argument("--scratch-mb", type=int, default=0, help="W scratch budget of the two-stage path (MiB, 0 = default)")
     return ap.parse_args()
 
 
@@ -172,7 +173,8 @@ def main():
     psi_t = torch.empty(full.psi_len, dtype=torch.float64, device=dev).uniform_(0.0, 1.0, generator=gp)
     sigma_t = torch.zeros(full.sigma_len, dtype=torch.float64, device=dev)
     arena = capi.Arena.adopt_device(arena_t.data_ptr(), arena_len, keep=arena_t)
-    plan = capi.Plan(arena, mine, full.psi_len, full.sigma_len, tile_n=args.tile_n, item_macs=args.item_macs)
+    plan = capi.Plan(arena, mine, full.psi_len, full.sigma_len, tile_n=args.tile_n, item_macs=args.item_macs,
+                     scratch_mb=args.scratch_mb)
     st = plan.stats
     log("compiled in %.1f s: %s" % (time.time() - t0, st))
     stream = torch.cuda.current_stream().cuda_stream

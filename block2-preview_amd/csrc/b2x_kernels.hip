@@ -16,6 +16,7 @@
 // in fixed order into psi' (psi' += scale * sum): no atomics, bitwise reproducible.
 #include "b2x_kernels.h"
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 namespace b2x {
 
@@ -299,13 +300,14 @@ __global__ __launch_bounds__(256, (TMF <= 2 ? 4 : (TMF <= 4 ? 3 : 2))) void hpsi
 // private to a wave and are prefetched one chunk ahead straight into registers.  Row tiles are cut at the
 // row-slice boundaries of the sector, so a segment's rows always cover its tile: only columns (B side)
 // and the k tail need masking, and both are applied to the B registers.
-template <int TMF, int CF, int NW>
+template <int TMF, int CF, int NW, int KC>
 __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GSeg *__restrict__ segs,
                                         const double *__restrict__ arena, const double *__restrict__ psi,
                                         double *__restrict__ scratch, double *__restrict__ slabs) {
     constexpr int TM = TMF * 16, NT = NW * 64;
-    constexpr int ABUF = TM * 16;        // doubles per LDS buffer (unpadded: the DMA image is lane-linear)
-    constexpr int NG = TM * 8;           // 16-byte granules per chunk
+    constexpr int KS = KC / 4;           // k-steps (MFMA K = 4) per chunk
+    constexpr int ABUF = TM * KC;        // doubles per LDS buffer (unpadded: the DMA image is lane-linear)
+    constexpr int NG = TM * KC / 2;      // 16-byte granules per chunk
     constexpr int NI = (NG + NT - 1) / NT; // DMA instructions per thread per chunk
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -318,7 +320,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         for (int q = 0; q < CF; q++)
             acc[f][q] = v4d{0.0, 0.0, 0.0, 0.0};
 
-    double bnxt[CF][4], bcur[CF][4];
+    double bnxt[CF][KS], bcur[CF][KS];
     // ---- per-segment state: 32-bit element offsets from wave-uniform bases --------------------------
     const double *sA = arena, *sB = arena;
     uint32_t aoff[NI];   // per DMA instruction: row part of the source offset
@@ -346,10 +348,11 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
                 const int row = 2 * (p ^ (8 * (kl & 1)));
                 aoff[j] = (uint32_t)min(row, S.mr - 1);
                 akq[j] = (uint32_t)kl * astep;
-            } else { // image [TM rows][16 k]; granule slot gs of row holds k = 2*(gs ^ ((row>>1)&7)), +1
-                const int row = G >> 3, gs = G & 7;
+            } else { // image [TM rows][KC k]; granule slot gs of a row holds k = 2*(gs ^ swz(row)), +1
+                const int row = G / (KC / 2), gs = G % (KC / 2);
+                const int swz = KC == 16 ? ((row >> 1) & 7) : (row & 15);
                 aoff[j] = (uint32_t)min(row, S.mr - 1) * (uint32_t)S.a_sr;
-                akq[j] = (uint32_t)(2 * (gs ^ ((row >> 1) & 7)));
+                akq[j] = (uint32_t)(2 * (gs ^ swz));
             }
         }
         colmask = 0;
@@ -379,34 +382,34 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         for (int q = 0; q < CF; q++) {
             uint32_t ko = (uint32_t)(kb + g) * bstep;
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
+            for (int s = 0; s < KS; s++) {
                 bnxt[q][s] = sB[boff[q] + min(ko, bkmax)];
                 ko += 4 * bstep;
             }
         }
-        bmasked = !cols_full || kb + 16 > S.K; // the k tail is neutralised on the B side
+        bmasked = !cols_full || kb + KC > S.K; // the k tail is neutralised on the B side
         if (bmasked) {
             bmask = 0;
 #pragma unroll
             for (int q = 0; q < CF; q++)
 #pragma unroll
-                for (int s = 0; s < 4; s++)
-                    bmask |= (uint32_t)(((colmask >> q) & 1) && kb + 4 * s + g < S.K) << (q * 4 + s);
+                for (int s = 0; s < KS; s++)
+                    bmask |= (uint32_t)(((colmask >> q) & 1) && kb + 4 * s + g < S.K) << (q * KS + s);
         }
     };
     auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < CF; q++)
 #pragma unroll
-            for (int s = 0; s < 4; s++)
-                bcur[q][s] = (!bmasked || ((bmask >> (q * 4 + s)) & 1)) ? bnxt[q][s] : 0.0;
+            for (int s = 0; s < KS; s++)
+                bcur[q][s] = (!bmasked || ((bmask >> (q * KS + s)) & 1)) ? bnxt[q][s] : 0.0;
     };
     // the MFMA block: all TMF x CF fragments, branch-free
     // Pin the issue order inside the MFMA block: LDS reads run LEAD fragments ahead of the MFMAs that consume
     // them.  Left alone, hipcc hoists all 4*TMF ds_reads to the top of the block (2 VGPRs each), which at
     // TMF = 16 exceeds the 256-VGPR budget of two waves per SIMD and spills inside the loop.
     auto pin_schedule = [&]() __attribute__((always_inline)) {
-        constexpr int LEAD = 6, NRD = 4 * TMF;
+        constexpr int LEAD = 6, NRD = KS * TMF;
         __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0); // DS reads
 #pragma unroll
         for (int i = 0; i < NRD - LEAD; i++) {
@@ -417,23 +420,23 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     };
     // The MFMA block: all TMF x CF fragments in ONE basic block for both image layouts (a branch over the
     // layouts would give every accumulator two definitions and hipcc then keeps two copies of the tile).
-    //   rowmaj image: (row, k) at row*16 + 2*((k>>1) ^ ((row>>1)&7)) + (k&1)
+    //   rowmaj image: (row, k) at row*KC + 2*((k>>1) ^ swz(row)) + (k&1),  swz = (row>>1)&7 (KC 16) or row&15 (KC 32)
     //   kmaj   image: (row, k) at k*TM + (row ^ 16*(k&1))
     // with row = f*16 + c, k = 4s + g.  Per k-step s a lane needs two bases (even / odd fragment, they differ
     // only for the kmaj swizzle) and a wave-uniform fragment stride.
     auto compute = [&](const double *As, bool kmaj) __attribute__((always_inline)) {
-        const int sw = (c >> 1) & 7;
-        const double *pe[4], *po[4];
+        const int sw = KC == 16 ? ((c >> 1) & 7) : c;
+        const double *pe[KS], *po[KS];
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
-            const int o_row = c * 16 + 2 * ((2 * s + (g >> 1)) ^ sw) + (g & 1);
+        for (int s = 0; s < KS; s++) {
+            const int o_row = c * KC + 2 * ((2 * s + (g >> 1)) ^ sw) + (g & 1);
             const int o_k = (4 * s + g) * TM + c;
             pe[s] = As + (kmaj ? o_k + 16 * (g & 1) : o_row);
             po[s] = As + (kmaj ? o_k - 16 * (g & 1) : o_row);
         }
-        const int sf = kmaj ? 16 : 256;
+        const int sf = kmaj ? 16 : 16 * KC;
 #pragma unroll
-        for (int s = 0; s < 4; s++)
+        for (int s = 0; s < KS; s++)
 #pragma unroll
             for (int f = 0; f < TMF; f++) {
                 double a = ((f & 1) ? po[s] : pe[s])[f * sf];
@@ -455,7 +458,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         __syncthreads(); // drains the DMA (vmcnt(0)) and publishes the image
         while (true) {
             uint32_t nsi = si;
-            int nkb = kb + 16;
+            int nkb = kb + KC;
             if (nkb >= S.K)
                 nsi = si + 1, nkb = 0;
             const bool more = nsi < item.seg_end;
@@ -497,22 +500,22 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
 
 // One launch per stage: every workgroup picks the body specialised for its item's tile height (64-row units), so
 // tiles of all heights share a grid (no per-variant launch tails) and one LDS allocation.
-template <int CF, int NW>
+template <int CF, int NW, int KC>
 __global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
                                                          const double *__restrict__ arena,
                                                          const double *__restrict__ psi, double *__restrict__ scratch,
                                                          double *__restrict__ slabs) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * 256 * 16];
+    __shared__ __attribute__((aligned(16))) double lds[2 * 256 * KC];
     const GItem item = items[blockIdx.x];
     const int v = (item.rows - 1) >> 6;
     if (v == 0)
-        gg_body<4, CF, NW>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<4, CF, NW, KC>(item, lds, segs, arena, psi, scratch, slabs);
     else if (v == 1)
-        gg_body<8, CF, NW>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<8, CF, NW, KC>(item, lds, segs, arena, psi, scratch, slabs);
     else if (v == 2)
-        gg_body<12, CF, NW>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<12, CF, NW, KC>(item, lds, segs, arena, psi, scratch, slabs);
     else
-        gg_body<16, CF, NW>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<16, CF, NW, KC>(item, lds, segs, arena, psi, scratch, slabs);
 }
 
 // psi'[tile] += scale * sum_i slab_i[tile]   (fixed order i = 0..n_items-1)
@@ -710,7 +713,9 @@ hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_beg
     const uint32_t n = v_begin[kGGVariants] - v_begin[0];
     if (n == 0)
         return hipSuccess;
-    hipLaunchKernelGGL((gg_kernel<1, kGGTileN / 16>), dim3(n), dim3(kGGTileN * 4), 0, st, segs, items + v_begin[0],
+    // chunk depth 16: a 32-deep chunk halves the barriers (+2 % on uniform 1024^3 pairs) but pads every K to 32 and
+    // spills at 256 VGPRs (-2 % on the M=4000 plan)
+    hipLaunchKernelGGL((gg_kernel<1, kGGTileN / 16, 16>), dim3(n), dim3(kGGTileN * 4), 0, st, segs, items + v_begin[0],
                        arena, psi, scratch, slabs);
     return hipGetLastError();
 }

@@ -318,7 +318,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     uint64_t gg_macs = 0;
     if (!big.empty()) {
         const int TN = kGGTileN;
-        const uint64_t budget = (uint64_t)(opt && opt->scratch_mb > 0 ? opt->scratch_mb : 4096) * (1u << 17);
+        const uint64_t budget = (uint64_t)(opt && opt->scratch_mb > 0 ? opt->scratch_mb : 16384) * (1u << 17);
         // work in component order; a super-step closes when the W scratch budget is reached
         struct PW {
             const Component *c;

@@ -89,7 +89,7 @@ typedef struct b2x_plan_options {
     int32_t kernel;               /* 0 = auto, 1 = scalar reference kernel, 2 = MFMA kernel */
     int64_t item_macs;            /* target MACs per work item (0 = auto) */
     int32_t two_stage;            /* 0 = auto (sectors taller than one fused tile), 1 = always, -1 = never */
-    int32_t scratch_mb;           /* W scratch budget of the two-stage path in MiB (0 = 4096) */
+    int32_t scratch_mb;           /* W scratch budget of the two-stage path in MiB (0 = 16384) */
     int32_t reserved[6];
 } b2x_plan_options;
 
