@@ -343,10 +343,9 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         for (int j = 0; j < NI; j++) {
             // granule G of the LDS image is written by lane `lane` of DMA instruction (wave, j)
             const int G = (wave * NI + j) * 64 + lane;
-            if (s_kmaj) { // image [k][TM rows]; granule = rows (2p', 2p'+1) of one k, p' = p ^ 8*(k&1)
-                const int kl = G / (TM / 2), p = G % (TM / 2);
-                const int row = 2 * (p ^ (8 * (kl & 1)));
-                aoff[j] = (uint32_t)min(row, S.mr - 1);
+            if (s_kmaj) { // fragment-major image [f][k][16 rows]: granule = rows (f*16 + 2p, +1) of one k
+                const int f = G / (KC * 8), kl = (G % (KC * 8)) >> 3, p2 = G & 7;
+                aoff[j] = (uint32_t)min(f * 16 + 2 * p2, S.mr - 1);
                 akq[j] = (uint32_t)kl * astep;
             } else { // image [TM rows][KC k]; granule slot gs of a row holds k = 2*(gs ^ swz(row)), +1
                 const int row = G / (KC / 2), gs = G % (KC / 2);
@@ -420,26 +419,25 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     };
     // The MFMA block: all TMF x CF fragments in ONE basic block for both image layouts (a branch over the
     // layouts would give every accumulator two definitions and hipcc then keeps two copies of the tile).
+    // Both images are fragment-major with the same fragment stride (16*KC doubles), so the ds_read of fragment f
+    // is base(lane, k-step) + an immediate:
     //   rowmaj image: (row, k) at row*KC + 2*((k>>1) ^ swz(row)) + (k&1),  swz = (row>>1)&7 (KC 16) or row&15 (KC 32)
-    //   kmaj   image: (row, k) at k*TM + (row ^ 16*(k&1))
-    // with row = f*16 + c, k = 4s + g.  Per k-step s a lane needs two bases (even / odd fragment, they differ
-    // only for the kmaj swizzle) and a wave-uniform fragment stride.
+    //   kmaj   image: (row, k) at (row>>4)*16*KC + k*16 + (row&15)         (conflict-free as it stands)
+    // with row = f*16 + c, k = 4s + g.
     auto compute = [&](const double *As, bool kmaj) __attribute__((always_inline)) {
         const int sw = KC == 16 ? ((c >> 1) & 7) : c;
-        const double *pe[KS], *po[KS];
+        const double *pb[KS];
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             const int o_row = c * KC + 2 * ((2 * s + (g >> 1)) ^ sw) + (g & 1);
-            const int o_k = (4 * s + g) * TM + c;
-            pe[s] = As + (kmaj ? o_k + 16 * (g & 1) : o_row);
-            po[s] = As + (kmaj ? o_k - 16 * (g & 1) : o_row);
+            const int o_k = (4 * s + g) * 16 + c;
+            pb[s] = As + (kmaj ? o_k : o_row);
         }
-        const int sf = kmaj ? 16 : 16 * KC;
 #pragma unroll
         for (int s = 0; s < KS; s++)
 #pragma unroll
             for (int f = 0; f < TMF; f++) {
-                double a = ((f & 1) ? po[s] : pe[s])[f * sf];
+                double a = pb[s][f * 16 * KC];
 #pragma unroll
                 for (int q = 0; q < CF; q++)
                     acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][s], acc[f][q], 0, 0, 0);
