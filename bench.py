@@ -230,7 +230,7 @@ def main():
                          "frac": round(ach / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": st["n_launches"],
                          "kernel": ("gg_kernel (two-stage grouped GEMM, all launches of one H.psi)"
-                                    if st["dominant_class"] >= 4 else "hpsi_main class %d" % st["dominant_class"]),
+                                    if st["macs_issued"] else "hpsi_wave class %d" % st["dominant_class"]),
                          "kernel_ms": round(k_ms, 3),
                          "useful_over_issued_mfma": round(st["macs"] / st["macs_issued"], 3) if st["macs_issued"] else None,
                          "executed_over_algorithmic_macs": round(st["macs_executed"] / max(1, st["macs"]), 3)},

@@ -38,9 +38,9 @@ struct b2x_plan {
     b2x_plan_stats stats{};
     bool fallback = false;
     int kernel = 0;
-    DPart *d_parts[kNumClasses] = {nullptr, nullptr, nullptr, nullptr};
-    DItem *d_items[kNumClasses] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t n_items[kNumClasses] = {0, 0, 0, 0};
+    DPart *d_parts[kNumClasses] = {nullptr, nullptr, nullptr};
+    DItem *d_items[kNumClasses] = {nullptr, nullptr, nullptr};
+    uint32_t n_items[kNumClasses] = {0, 0, 0};
     DTile *d_tiles = nullptr;
     uint32_t n_tiles = 0;
     double *d_slabs = nullptr;

@@ -1,19 +1,14 @@
 // b2x_kernels.hip — CDNA4 (gfx950) kernels of the H·psi plan replay.
 //
-// hpsi_main<NW, TMF, K1F>: one workgroup (NW waves) per work item.  A work item is a slice of the
-// part list of ONE output tile (TMF*16 rows x NW*16 columns of psi').  Wave w owns the 16-column
-// strip w of the tile and, for every part
-//     stage 0   W(k1c x 16)  = alpha * X(k1c x k0) * op(Y)(k0 x 16)      fp64 MFMA 16x16x4
-//     stage 1   V(mr  x 16) += op(Z)(mr x k1c) * W(k1c x 16)              fp64 MFMA 16x16x4
-// The stage-0 accumulator IS the stage-1 B operand: v_mfma_f64_16x16x4_f64 keeps C/D as
-// row = (lane>>4) + 4*reg, col = lane&15, and takes B as B[k = lane>>4][col = lane&15], so
-// register `reg` of a W fragment is exactly the B fragment of the k-step {4*reg + (lane>>4)}.
-// W therefore never leaves the register file (the reference round-trips it through a per-thread
-// work array, src/core/batch_gemm.hpp:1630-1635).  The A operands (X and op(Z) chunks, shared by all
-// strips of the tile) are staged through LDS with coalesced loads; op(Y) strips are private to a
-// wave and go straight from L2/HBM into registers.
-// Accumulators of an item are written to its partial slab; hpsi_reduce sums the slabs of each tile
-// in fixed order into psi' (psi' += scale * sum): no atomics, bitwise reproducible.
+//   hpsi_wave<TMF,K1F,CF>   fused pair kernel, one WAVE per work item (sectors up to 128 rows): stage 0
+//                           W = alpha X op(Y) and stage 1 V += op(Z) W on v_mfma_f64_16x16x4_f64; the stage-0
+//                           accumulator IS the stage-1 B operand (C/D layout row = (lane>>4) + 4*reg, col = lane&15
+//                           equals the B-fragment layout of k-step `reg`), so W never leaves the register file
+//                           (the reference round-trips it through a per-thread work array, batch_gemm.hpp:1630-1635)
+//   gg_kernel<CF,NW,KC>     grouped GEMM of the two-stage path (tall sectors): LDS-DMA staged A, register B
+//   hpsi_reduce             psi'[tile] += scale * sum of the tile's partial slabs, fixed order (no atomics)
+//   hpsi_generic            per-pair atomic kernel: on-device cross-check / fallback for unsegmentable plans
+//   diag_build_k, vec_*     diagonal of H_eff and BLAS-1 for the device-resident Davidson
 #include "b2x_kernels.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
@@ -21,135 +16,6 @@
 namespace b2x {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-
-template <int NW, int TMF, int K1F>
-__global__ __launch_bounds__(NW * 64) void hpsi_main(const DPart *__restrict__ parts, const DItem *__restrict__ items,
-                                                       const double *__restrict__ arena,
-                                                       const double *__restrict__ psi, double *__restrict__ slabs) {
-    constexpr int NT = NW * 64, TM = TMF * 16, K1C = K1F * 16;
-    constexpr int LDX = 18;                              // Xs[row][k], 18 == 2 mod 32 doubles: conflict-free b64 reads
-    constexpr int LDZT = (TM % 32 == 0) ? TM + 16 : TM;  // Zs[k][row] layout for transposed Z, == 16 mod 32
-    constexpr int ZS_N = TM * LDX, ZS_T = 16 * LDZT;
-    constexpr int ZS = ZS_N > ZS_T ? ZS_N : ZS_T;
-    __shared__ double lds[K1C * LDX + ZS];
-    double *Xs = lds, *Zs = lds + K1C * LDX;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int g = lane >> 4, c = lane & 15;
-    const DItem item = items[blockIdx.x];
-
-    v4d acc[TMF];
-#pragma unroll
-    for (int f = 0; f < TMF; f++)
-        acc[f] = v4d{0.0, 0.0, 0.0, 0.0};
-
-    for (uint32_t pi = item.part_begin; pi < item.part_end; pi++) {
-        const DPart P = parts[pi];
-        const int k0 = P.k0, mr = P.mr, nc = P.nc, tr0 = P.tr0, tc0 = P.tc0;
-        const int cabs = wave * 16 + c;
-        const bool col_ok = cabs >= tc0 && cabs < tc0 + nc;
-        const bool wave_on = (wave * 16 + 16 > tc0) && (wave * 16 < tc0 + nc);
-        const double *ypc = arena + P.y_off + (int64_t)min(max(cabs - tc0, 0), nc - 1) * P.scy; // clamped column
-        const int f_lo = tr0 >> 4, f_hi = (tr0 + mr + 15) >> 4; // row fragments touched by this part
-        const bool zt = (P.srz == 1 && P.skz != 1);             // op(Z) stored k-major (transposed block)
-        const int lsr = zt ? 1 : LDX, lsk = zt ? LDZT : 1;
-
-        for (int k1lo = 0; k1lo < P.k1; k1lo += K1C) {
-            const int k1c = min(K1C, P.k1 - k1lo);
-            const double *xp = psi + P.x_off + (int64_t)k1lo * P.ldx;
-            const double *zp = arena + P.z_off + (int64_t)k1lo * P.skz;
-
-            v4d w[K1F];
-#pragma unroll
-            for (int f = 0; f < K1F; f++)
-                w[f] = v4d{0.0, 0.0, 0.0, 0.0};
-
-            // ---------------- stage 0: W = X * op(Y), k0 in chunks of 16 ---------------------
-            for (int kb = 0; kb < k0; kb += 16) {
-                __syncthreads(); // readers of the previous Xs / Zs chunk are done
-                for (int idx = tid; idx < K1C * 16; idx += NT) {
-                    int row = idx >> 4, kk = idx & 15;
-                    double v = xp[(int64_t)min(row, k1c - 1) * P.ldx + min(kb + kk, k0 - 1)];
-                    Xs[row * LDX + kk] = (row < k1c && kb + kk < k0) ? v : 0.0;
-                }
-                double b[4];
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    int k = kb + 4 * s + g;
-                    double v = ypc[(int64_t)min(k, k0 - 1) * P.sky];
-                    b[s] = v * ((col_ok && k < k0) ? 1.0 : 0.0); // mask-multiply keeps the load unconditional
-                }
-                __syncthreads();
-                if (wave_on) {
-#pragma unroll
-                    for (int s = 0; s < 4; s++) {
-#pragma unroll
-                        for (int f = 0; f < K1F; f++)
-                            if (f * 16 < k1c) {
-                                double a = Xs[(f * 16 + c) * LDX + 4 * s + g];
-                                w[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s], w[f], 0, 0, 0);
-                            }
-                    }
-                }
-            }
-#pragma unroll
-            for (int f = 0; f < K1F; f++)
-                w[f] *= P.alpha;
-
-            // ---------------- stage 1: V += op(Z) * W, k1c in chunks of 16 -------------------
-#pragma unroll
-            for (int f1 = 0; f1 < K1F; f1++) {
-                if (f1 * 16 < k1c) {
-                    const int kc = f1 * 16;
-                    __syncthreads();
-                    const int r_lo = f_lo * 16, n_rows = (f_hi - f_lo) * 16;
-                    if (!zt) {
-                        for (int idx = tid; idx < n_rows * 16; idx += NT) {
-                            int row = r_lo + (idx >> 4), kk = idx & 15;
-                            int rr = row - tr0;
-                            double v = zp[(int64_t)min(max(rr, 0), mr - 1) * P.srz +
-                                          (int64_t)min(kc + kk, k1c - 1) * P.skz];
-                            Zs[row * LDX + kk] = (rr >= 0 && rr < mr && kc + kk < k1c) ? v : 0.0;
-                        }
-                    } else {
-                        for (int idx = tid; idx < n_rows * 16; idx += NT) {
-                            int kk = idx / n_rows, row = r_lo + idx % n_rows;
-                            int rr = row - tr0;
-                            double v = zp[(int64_t)min(max(rr, 0), mr - 1) + (int64_t)min(kc + kk, k1c - 1) * P.skz];
-                            Zs[kk * LDZT + row] = (rr >= 0 && rr < mr && kc + kk < k1c) ? v : 0.0;
-                        }
-                    }
-                    __syncthreads();
-                    if (wave_on) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++) {
-                            const double bw = w[f1][r];
-#pragma unroll
-                            for (int f = 0; f < TMF; f++)
-                                if (f >= f_lo && f < f_hi) {
-                                    double a = Zs[(f * 16 + c) * lsr + (4 * r + g) * lsk];
-                                    acc[f] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bw, acc[f], 0, 0, 0);
-                                }
-                        }
-                    }
-                }
-            }
-        }
-    }
-    // ---------------- epilogue: accumulators -> partial slab ----------------------------------
-    double *slab = slabs + item.slab_off;
-    const int col = wave * 16 + c;
-    if (col < item.cols) {
-#pragma unroll
-        for (int f = 0; f < TMF; f++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int row = f * 16 + 4 * r + g;
-                if (row < item.rows)
-                    slab[(int64_t)row * item.cols + col] = acc[f][r];
-            }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // hpsi_wave<TMF, K1F, CF>: the wavefront-level grouped GEMM for small symmetry blocks.  ONE WAVE per work
@@ -698,9 +564,6 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
         return launch_wave_t<4, 2, 2>(parts, items, n_items, arena, psi, slabs, st);
     case 2:
         return launch_wave_t<8, 2, 2>(parts, items, n_items, arena, psi, slabs, st);
-    case 3:
-        hipLaunchKernelGGL((hpsi_main<8, 16, 8>), dim3(n_items), dim3(512), 0, st, parts, items, arena, psi, slabs);
-        return hipGetLastError();
     }
     return hipErrorInvalidValue;
 }

@@ -180,8 +180,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         std::vector<double> cost;
     };
     int64_t total_cost = 0;
-    uint64_t cls_macs[kNumClasses] = {0, 0, 0, 0};
-    double cls_alg[kNumClasses] = {0, 0, 0, 0};
+    uint64_t cls_macs[kNumClasses] = {0, 0, 0};
+    double cls_alg[kNumClasses] = {0, 0, 0};
     std::vector<HostTile> htiles;
     std::vector<const Component *> big; // components routed to the two-stage path
     const int two_stage = opt ? opt->two_stage : 0;
@@ -191,7 +191,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         int max_k0 = 0;
         for (uint32_t wi = c.w_begin; wi < c.w_end; wi++)
             max_k0 = std::max(max_k0, (int)pairs[win[wi].pair].k0);
-        const bool large = c.rows > kClasses[kNumClasses - 1].tmf * 16 || c.cols > 128 || max_k0 > 512;
+        const bool large = c.rows > 128 || c.cols > 128 || max_k0 > 512;
         if (two_stage > 0 || (two_stage == 0 && large)) {
             big.push_back(&c);
             continue;
@@ -199,16 +199,14 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         // class by shape: columns decide the number of waves, rows the fragment count
         int cls;
         if (opt && opt->tile_n > 0) { // forced class (tests): 16 -> 32x32 wave, 32 -> 128x32 wave, 64 -> 64x32 wave
-            cls = opt->tile_n <= 16 ? 0 : (opt->tile_n <= 32 ? 2 : (opt->tile_n <= 64 ? 1 : 3));
+            cls = opt->tile_n <= 16 ? 0 : (opt->tile_n <= 32 ? 2 : 1);
         } else {
             if (c.cols <= 32 && c.rows <= 32)
                 cls = 0;
             else if (c.rows <= 64)
                 cls = 1;
-            else if (c.rows <= 128)
-                cls = 2;
             else
-                cls = 3;
+                cls = 2; // (sectors taller than 128 rows only get here when the two-stage path is disabled)
         }
         const KClass &K = kClasses[cls];
         const int TM = K.tmf * 16, TN = K.nw * 16, K1C = K.k1f * 16;
@@ -505,7 +503,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         if (cls_macs[k] > cls_macs[st.dominant_class])
             st.dominant_class = k;
     }
-    st.macs_executed = cls_macs[0] + cls_macs[1] + cls_macs[2] + cls_macs[3] + gg_macs;
+    st.macs_executed = cls_macs[0] + cls_macs[1] + cls_macs[2] + gg_macs;
     st.macs_dominant = cls_macs[st.dominant_class];
     st.macs_alg_dominant = (uint64_t)(cls_alg[st.dominant_class] + 0.5);
     st.n_launches = 1;

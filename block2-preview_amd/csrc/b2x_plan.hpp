@@ -81,15 +81,15 @@ struct SuperStep {
 static const int kGGTileM = 256, kGGTileN = 128;
 
 // kernel classes of the fused path.  nw = tile width / 16, tmf = tile height / 16, k1f = k1 chunk / 16.
-//   wave = true : hpsi_wave — one WAVE per work item, operands straight from L2 into MFMA fragments, no LDS,
-//                 no barriers (the wavefront-level grouped GEMM for the many small symmetry blocks)
-//   wave = false: hpsi_main — one 8-wave workgroup per item, A operands staged through LDS
+// All fused classes run hpsi_wave — one WAVE per work item, operands straight from L2 into MFMA fragments, no LDS,
+// no barriers (the wavefront-level grouped GEMM for the many small symmetry blocks).  Sectors taller than 128 rows
+// (or wider / deeper than one tile handles well) go to the two-stage grouped-GEMM path instead.
 struct KClass {
     int nw, tmf, k1f;
     bool wave;
 };
-static const KClass kClasses[] = {{2, 2, 2, true}, {2, 4, 2, true}, {2, 8, 2, true}, {8, 16, 8, false}};
-static const int kNumClasses = 4;
+static const KClass kClasses[] = {{2, 2, 2, true}, {2, 4, 2, true}, {2, 8, 2, true}};
+static const int kNumClasses = 3;
 
 struct ClassWork {
     std::vector<DPart> parts;
@@ -100,7 +100,7 @@ struct CompiledPlan {
     ClassWork cls[kNumClasses];
     std::vector<DTile> tiles;
     uint64_t slab_elems = 0;
-    uint64_t cls_macs[kNumClasses] = {0, 0, 0, 0}; // MACs the kernels of each class execute
+    uint64_t cls_macs[kNumClasses] = {0, 0, 0}; // MACs the kernels of each class execute
     b2x_plan_stats stats{};
     // two-stage path
     std::vector<GSeg> gsegs;
