@@ -52,9 +52,6 @@ struct b2x_plan {
     DTile *d_gtiles = nullptr;
     double *d_scratch = nullptr, *d_gslabs = nullptr;
     std::vector<SuperStep> steps;
-    // the fused kernel classes and the two-stage sequence write disjoint sectors of psi': they run concurrently
-    hipStream_t aux[kNumClasses] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[kNumClasses] = {nullptr, nullptr, nullptr};
     double *d_psi = nullptr, *d_sigma = nullptr; // staging for host-pointer execute
     size_t psi_len = 0, sigma_len = 0;
     int dominant_cls = 0;
@@ -67,14 +64,6 @@ static void plan_free(b2x_plan *p) {
         if (p->d_items[k])
             (void)hipFree(p->d_items[k]);
     }
-    for (int k = 0; k < kNumClasses; k++) {
-        if (p->aux[k])
-            (void)hipStreamDestroy(p->aux[k]);
-        if (p->ev_join[k])
-            (void)hipEventDestroy(p->ev_join[k]);
-    }
-    if (p->ev_fork)
-        (void)hipEventDestroy(p->ev_fork);
     if (p->d_tiles)
         (void)hipFree(p->d_tiles);
     if (p->d_slabs)
@@ -308,42 +297,14 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
         HIPCHK(launch_generic(p->d_pairs, p->n_pairs, p->arena->dev, psi, sigma, scale, st));
         return B2X_OK;
     }
-    // fork: every non-empty fused class on its own stream, the two-stage sequence on the caller's stream
-    int n_fused = 0;
     for (int k = 0; k < kNumClasses; k++)
-        n_fused += p->n_items[k] != 0;
-    const bool fork = n_fused > 1 || (n_fused == 1 && !p->steps.empty());
-    if (fork) {
-        if (!p->ev_fork) {
-            HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
-            for (int k = 0; k < kNumClasses; k++) {
-                HIPCHK(hipStreamCreateWithFlags(&p->aux[k], hipStreamNonBlocking));
-                HIPCHK(hipEventCreateWithFlags(&p->ev_join[k], hipEventDisableTiming));
-            }
-        }
-        HIPCHK(hipEventRecord(p->ev_fork, st));
-    }
-    for (int k = 0; k < kNumClasses; k++) {
-        if (p->n_items[k] == 0)
-            continue;
-        hipStream_t sk = fork ? p->aux[k] : st;
-        if (fork)
-            HIPCHK(hipStreamWaitEvent(sk, p->ev_fork, 0));
-        HIPCHK(launch_main(k, p->d_parts[k], p->d_items[k], p->n_items[k], p->arena->dev, psi, p->d_slabs, sk));
-        if (fork)
-            HIPCHK(hipEventRecord(p->ev_join[k], sk));
-    }
+        HIPCHK(launch_main(k, p->d_parts[k], p->d_items[k], p->n_items[k], p->arena->dev, psi, p->d_slabs, st));
+    HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma, scale, st));
     for (const SuperStep &ss : p->steps) {
         HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, st));
         HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, st));
         HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st));
     }
-    // join, then add the fused tiles' slabs into psi'
-    if (fork)
-        for (int k = 0; k < kNumClasses; k++)
-            if (p->n_items[k] != 0)
-                HIPCHK(hipStreamWaitEvent(st, p->ev_join[k], 0));
-    HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma, scale, st));
     return B2X_OK;
 }
 
