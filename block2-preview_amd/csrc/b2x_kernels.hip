@@ -16,6 +16,7 @@
 namespace b2x {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double d4u __attribute__((ext_vector_type(4), aligned(8))); // 4 consecutive doubles, 8-byte aligned
 
 // ------------------------------------------------------------------------------------------------
 // hpsi_wave<TMF, K1F, CF>: the wavefront-level grouped GEMM for small symmetry blocks.  ONE WAVE per work
@@ -25,7 +26,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // is chained from the stage-0 accumulator into the stage-1 B operand inside the register file, and the
 // memory latency of these short K loops is hidden by the other waves of the SIMD (<= 128 VGPRs).
 template <int TMF, int K1F, int CF>
-__global__ __launch_bounds__(256, (TMF <= 2 ? 4 : (TMF <= 4 ? 3 : 2))) void hpsi_wave(const DPart *__restrict__ parts, const DItem *__restrict__ items,
+__global__ __launch_bounds__(256, 2) void hpsi_wave(const DPart *__restrict__ parts, const DItem *__restrict__ items,
                                                   uint32_t n_items, const double *__restrict__ arena,
                                                   const double *__restrict__ psi, double *__restrict__ slabs) {
     const int lane = threadIdx.x & 63;
@@ -67,27 +68,62 @@ __global__ __launch_bounds__(256, (TMF <= 2 ? 4 : (TMF <= 4 ? 3 : 2))) void hpsi
 #pragma unroll
                 for (int q = 0; q < CF; q++)
                     w[f][q] = v4d{0.0, 0.0, 0.0, 0.0};
-            // per-lane X row of every k1 fragment (rows >= k1c read a valid row; their W rows are
-            // neutralised in stage 1, where op(Z) is zeroed for k >= k1c)
+            // MFMA operand lanes are loaded in a permuted order so that every lane reads CONTIGUOUS k:
+            //  * stage 0, k-step s of a 16-k trip: lane group g supplies k = kb + 4g + s (A and B alike), i.e. a lane
+            //    reads X[row][kb+4g .. +3] (32 B) instead of four 8-byte gathers;
+            //  * the X row fed to MFMA row i is f*16 + pi(i), pi(i) = 4*(i&3) + (i>>2), which makes accumulator
+            //    register r of lane group g hold W row f*16 + 4g + r — so in stage 1 lane group g needs
+            //    op(Z)[row][f1*16 + 4g .. +3], again 32 contiguous bytes.
+            // Rows >= k1c read a valid row; their W rows are neutralised in stage 1 (op(Z) zeroed for k >= k1c).
+            const int pi_c = 4 * (c & 3) + (c >> 2);
             uint32_t xoff[K1F];
 #pragma unroll
             for (int f = 0; f < K1F; f++)
-                xoff[f] = (uint32_t)min(f * 16 + c, k1c - 1) * (uint32_t)P.ldx;
+                xoff[f] = (uint32_t)min(f * 16 + pi_c, k1c - 1) * (uint32_t)P.ldx;
+            const bool ywide = (P.sky == 1); // op(Y) stored k-contiguous
             // ---------------- stage 0: W = X * op(Y), 16 k per trip: all loads of the trip first ----------------
             for (int kb = 0; kb < k0; kb += 16) {
                 double b[4][CF], a[4][K1F];
+                if (kb + 16 <= k0) { // full trip: wide loads, no k masking
+                    const uint32_t kk = (uint32_t)(kb + 4 * g);
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const int k = kb + 4 * s + g;
-                    const uint32_t kc = (uint32_t)min(k, k0 - 1);
+                    for (int f = 0; f < K1F; f++) {
+                        const d4u v = *(const d4u *)(X + xoff[f] + kk);
 #pragma unroll
-                    for (int q = 0; q < CF; q++) {
-                        double v = Y[kc * (uint32_t)P.sky + yoff[q]];
-                        b[s][q] = (cok[q] && k < k0) ? v : 0.0; // k tail / columns outside the window: zero on the B side
+                        for (int s = 0; s < 4; s++)
+                            a[s][f] = v[s];
                     }
+                    if (ywide) {
 #pragma unroll
-                    for (int f = 0; f < K1F; f++)
-                        a[s][f] = X[xoff[f] + kc];
+                        for (int q = 0; q < CF; q++) {
+                            const d4u v = *(const d4u *)(Y + yoff[q] + kk);
+#pragma unroll
+                            for (int s = 0; s < 4; s++)
+                                b[s][q] = cok[q] ? v[s] : 0.0;
+                        }
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; s++)
+#pragma unroll
+                            for (int q = 0; q < CF; q++) {
+                                double v = Y[(kk + s) * (uint32_t)P.sky + yoff[q]];
+                                b[s][q] = cok[q] ? v : 0.0;
+                            }
+                    }
+                } else { // k tail: clamped 8-byte loads, k >= k0 zeroed on the B side
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const int k = kb + 4 * g + s;
+                        const uint32_t kc = (uint32_t)min(k, k0 - 1);
+#pragma unroll
+                        for (int q = 0; q < CF; q++) {
+                            double v = Y[kc * (uint32_t)P.sky + yoff[q]];
+                            b[s][q] = (cok[q] && k < k0) ? v : 0.0;
+                        }
+#pragma unroll
+                        for (int f = 0; f < K1F; f++)
+                            a[s][f] = X[xoff[f] + kc];
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < 4; s++)
@@ -112,27 +148,35 @@ __global__ __launch_bounds__(256, (TMF <= 2 ? 4 : (TMF <= 4 ? 3 : 2))) void hpsi
                 rok[f] = rr >= 0 && rr < mr;
                 zoff[f] = (uint32_t)min(max(rr, 0), mr - 1) * (uint32_t)P.srz;
             }
+            const bool zwide = (P.skz == 1); // op(Z) stored k-contiguous
 #pragma unroll
             for (int f1 = 0; f1 < K1F; f1++)
                 if (f1 * 16 < k1c) {
+                    // a[r] = op(Z)[row f*16+c][f1*16 + 4g + r], one row fragment at a time (8 VGPRs in flight per f)
+                    const bool zfull = zwide && f1 * 16 + 16 <= k1c;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int k = f1 * 16 + 4 * r + g;
-                        const uint32_t kz = (uint32_t)min(k, k1c - 1) * (uint32_t)P.skz;
-                        double a[TMF];
+                    for (int f = 0; f < TMF; f++)
+                        if (f >= f_lo && f < f_hi) {
+                            double a[4];
+                            if (zfull) {
+                                const d4u v = *(const d4u *)(Z + zoff[f] + (uint32_t)(f1 * 16 + 4 * g));
 #pragma unroll
-                        for (int f = 0; f < TMF; f++) { // fragments outside the part's row window load a valid row and are zeroed
-                            double v = Z[zoff[f] + kz];
-                            a[f] = (rok[f] && k < k1c) ? v : 0.0;
-                        }
+                                for (int r = 0; r < 4; r++)
+                                    a[r] = rok[f] ? v[r] : 0.0;
+                            } else {
 #pragma unroll
-                        for (int f = 0; f < TMF; f++)
-                            if (f >= f_lo && f < f_hi) {
+                                for (int r = 0; r < 4; r++) {
+                                    const int k = f1 * 16 + 4 * g + r;
+                                    double v = Z[zoff[f] + (uint32_t)min(k, k1c - 1) * (uint32_t)P.skz];
+                                    a[r] = (rok[f] && k < k1c) ? v : 0.0;
+                                }
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
 #pragma unroll
                                 for (int q = 0; q < CF; q++)
-                                    acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[f], w[f1][q][r], acc[f][q], 0, 0, 0);
-                            }
-                    }
+                                    acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[r], w[f1][q][r], acc[f][q], 0, 0, 0);
+                        }
                 }
         }
     }
