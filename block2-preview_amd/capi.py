@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from .planfile import PAIR_DTYPE
+from .planfile import GEMM_DTYPE, PAIR_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libb2x.so")
@@ -21,6 +21,7 @@ DECLARED_SYMBOLS = [
     "b2x_arena_create", "b2x_arena_adopt_device", "b2x_arena_resolve", "b2x_arena_len",
     "b2x_arena_device_ptr", "b2x_arena_destroy",
     "b2x_plan_create", "b2x_plan_execute", "b2x_plan_get_stats", "b2x_plan_time_kernel", "b2x_plan_destroy",
+    "b2x_gemm_plan_create",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
     "b2x_vec_multi_dot", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
 ]
@@ -177,6 +178,33 @@ class Plan:
             self.close()
         except Exception:
             pass
+
+
+class GemmPlan(Plan):
+    """Device-resident single-GEMM list (batch[1] of BatchGEMMSeq after a partial multiply, before auto_perform(v)):
+    out += scale * sum_i alpha_i op(A_i) op(B_i), operands from the arena or the input vector."""
+
+    def __init__(self, arena, gemms, in_len, out_len, item_macs=0):
+        gemms = np.ascontiguousarray(gemms, GEMM_DTYPE)
+        opt = PlanOptions()
+        opt.item_macs = item_macs
+        h = C.c_void_p()
+        check(lib().b2x_gemm_plan_create(C.byref(h), arena._h, C.c_size_t(len(gemms)), _ptr(gemms), C.c_size_t(in_len),
+                                         C.c_size_t(out_len), C.byref(opt)))
+        self._h, self._arena = h, arena
+        self.psi_len, self.sigma_len = in_len, out_len
+
+
+def debug_compile_and_emulate_gemms(gemms, in_len, out_len, arena, vin, vout, scale=1.0, item_macs=0):
+    """TEST HOOK: compile a single-GEMM list and evaluate the compiled work list with host loops."""
+    gemms = np.ascontiguousarray(gemms, GEMM_DTYPE)
+    opt = PlanOptions()
+    opt.item_macs = item_macs
+    st = PlanStats()
+    check(lib().b2x_debug_compile_and_emulate_gemms(
+        C.c_size_t(len(gemms)), _ptr(gemms), C.c_size_t(in_len), C.c_size_t(out_len), C.c_uint64(arena.size),
+        _ptr(arena), _ptr(vin), _ptr(vout), C.c_double(scale), C.byref(opt), C.byref(st)))
+    return st.as_dict()
 
 
 def debug_compile_and_emulate(pairs, psi_len, sigma_len, arena, psi, sigma, scale=1.0, tile_n=0, item_macs=0,

@@ -55,6 +55,7 @@ struct b2x_plan {
     double *d_psi = nullptr, *d_sigma = nullptr; // staging for host-pointer execute
     size_t psi_len = 0, sigma_len = 0;
     int dominant_cls = 0;
+    bool seg_scaled = false; // single-GEMM list plan (gg_kernel SCALED variant)
 };
 
 static void plan_free(b2x_plan *p) {
@@ -95,6 +96,64 @@ template <typename T> static int upload(T **dst, const std::vector<T> &src) {
     return B2X_OK;
 }
 
+// upload a compiled plan (work lists + scratch / slab buffers) and hand it out
+static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPlan &cp, size_t n_pairs, const b2x_pair *pairs,
+                       size_t psi_len, size_t sigma_len, const b2x_plan_options *opt) {
+    int rc = B2X_OK;
+    b2x_plan *p = new b2x_plan();
+    p->arena = arena, p->stats = cp.stats, p->psi_len = psi_len, p->sigma_len = sigma_len;
+    p->kernel = opt ? opt->kernel : 0;
+    p->fallback = pairs != nullptr && (cp.fallback || p->kernel == 1);
+    p->n_pairs = (uint32_t)n_pairs;
+    p->seg_scaled = cp.seg_scaled;
+    if (p->fallback) {
+        std::vector<b2x_pair> pv(pairs, pairs + n_pairs);
+        rc = upload(&p->d_pairs, pv);
+    } else {
+        size_t best = 0;
+        for (int k = 0; k < kNumClasses && rc == B2X_OK; k++) {
+            rc = upload(&p->d_parts[k], cp.cls[k].parts);
+            if (rc == B2X_OK)
+                rc = upload(&p->d_items[k], cp.cls[k].items);
+            p->n_items[k] = (uint32_t)cp.cls[k].items.size();
+            (void)best;
+        }
+        p->dominant_cls = (int)cp.stats.dominant_class;
+        if (rc == B2X_OK)
+            rc = upload(&p->d_tiles, cp.tiles);
+        p->n_tiles = (uint32_t)cp.tiles.size();
+        if (rc == B2X_OK)
+            rc = upload(&p->d_gsegs, cp.gsegs);
+        if (rc == B2X_OK)
+            rc = upload(&p->d_gitems, cp.gitems);
+        if (rc == B2X_OK)
+            rc = upload(&p->d_gtiles, cp.gtiles);
+        p->steps = cp.steps;
+        if (rc == B2X_OK && cp.scratch_elems) {
+            hipError_t e = hipMalloc((void **)&p->d_scratch, (cp.scratch_elems + 8) * sizeof(double));
+            if (e != hipSuccess)
+                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(W scratch): ") + hipGetErrorString(e));
+        }
+        if (rc == B2X_OK && cp.gslab_elems) {
+            hipError_t e = hipMalloc((void **)&p->d_gslabs, cp.gslab_elems * sizeof(double));
+            if (e != hipSuccess)
+                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
+        }
+        if (rc == B2X_OK && cp.slab_elems) {
+            hipError_t e = hipMalloc((void **)&p->d_slabs, cp.slab_elems * sizeof(double));
+            if (e != hipSuccess)
+                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
+        }
+    }
+    if (rc != B2X_OK) {
+        plan_free(p);
+        return rc;
+    }
+    *out = p;
+    return B2X_OK;
+}
+
+
 extern "C" {
 
 const char *b2x_last_error(void) { return g_err.c_str(); }
@@ -128,7 +187,7 @@ int b2x_device_sync(void) {
     return B2X_OK;
 }
 int b2x_device_alloc(void **dptr, size_t bytes) {
-    HIPCHK(hipMalloc(dptr, bytes ? bytes : 8));
+    HIPCHK(hipMalloc(dptr, bytes + 64)); // slack: the kernels fetch 16-byte granules
     return B2X_OK;
 }
 int b2x_device_free(void *dptr) {
@@ -240,56 +299,22 @@ int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, cons
     int rc = compile_plan(n_pairs, pairs, psi_len, sigma_len, arena->len, opt, cp, err);
     if (rc != B2X_OK)
         return fail(rc, "b2x_plan_create: " + err);
-    b2x_plan *p = new b2x_plan();
-    p->arena = arena, p->stats = cp.stats, p->psi_len = psi_len, p->sigma_len = sigma_len;
-    p->kernel = opt ? opt->kernel : 0;
-    p->fallback = cp.fallback || p->kernel == 1;
-    p->n_pairs = (uint32_t)n_pairs;
-    if (p->fallback) {
-        std::vector<b2x_pair> pv(pairs, pairs + n_pairs);
-        rc = upload(&p->d_pairs, pv);
-    } else {
-        size_t best = 0;
-        for (int k = 0; k < kNumClasses && rc == B2X_OK; k++) {
-            rc = upload(&p->d_parts[k], cp.cls[k].parts);
-            if (rc == B2X_OK)
-                rc = upload(&p->d_items[k], cp.cls[k].items);
-            p->n_items[k] = (uint32_t)cp.cls[k].items.size();
-            (void)best;
-        }
-        p->dominant_cls = (int)cp.stats.dominant_class;
-        if (rc == B2X_OK)
-            rc = upload(&p->d_tiles, cp.tiles);
-        p->n_tiles = (uint32_t)cp.tiles.size();
-        if (rc == B2X_OK)
-            rc = upload(&p->d_gsegs, cp.gsegs);
-        if (rc == B2X_OK)
-            rc = upload(&p->d_gitems, cp.gitems);
-        if (rc == B2X_OK)
-            rc = upload(&p->d_gtiles, cp.gtiles);
-        p->steps = cp.steps;
-        if (rc == B2X_OK && cp.scratch_elems) {
-            hipError_t e = hipMalloc((void **)&p->d_scratch, (cp.scratch_elems + 8) * sizeof(double));
-            if (e != hipSuccess)
-                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(W scratch): ") + hipGetErrorString(e));
-        }
-        if (rc == B2X_OK && cp.gslab_elems) {
-            hipError_t e = hipMalloc((void **)&p->d_gslabs, cp.gslab_elems * sizeof(double));
-            if (e != hipSuccess)
-                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
-        }
-        if (rc == B2X_OK && cp.slab_elems) {
-            hipError_t e = hipMalloc((void **)&p->d_slabs, cp.slab_elems * sizeof(double));
-            if (e != hipSuccess)
-                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
-        }
-    }
-    if (rc != B2X_OK) {
-        plan_free(p);
-        return rc;
-    }
-    *out = p;
-    return B2X_OK;
+    return plan_upload(out, arena, cp, n_pairs, pairs, psi_len, sigma_len, opt);
+}
+
+int b2x_gemm_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_gemms, const b2x_gemm *gemms, size_t in_len,
+                         size_t out_len, const b2x_plan_options *opt) {
+    if (!out || !arena || (n_gemms && !gemms))
+        return fail(B2X_ERR_INVALID, "b2x_gemm_plan_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(B2X_ERR_DEVICE, "b2x_gemm_plan_create: no HIP device (this path has no CPU fallback)");
+    CompiledPlan cp;
+    std::string err;
+    int rc = compile_gemm_list(n_gemms, gemms, in_len, out_len, arena->len, opt, cp, err);
+    if (rc != B2X_OK)
+        return fail(rc, "b2x_gemm_plan_create: " + err);
+    return plan_upload(out, arena, cp, 0, nullptr, in_len, out_len, nullptr);
 }
 
 static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale, hipStream_t st) {
@@ -301,8 +326,8 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
         HIPCHK(launch_main(k, p->d_parts[k], p->d_items[k], p->n_items[k], p->arena->dev, psi, p->d_slabs, st));
     HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma, scale, st));
     for (const SuperStep &ss : p->steps) {
-        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, st));
-        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, st));
+        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, st));
+        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, st));
         HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st));
     }
     return B2X_OK;
@@ -360,9 +385,9 @@ int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, 
             HIPCHK(hipEventRecord(e0, st));
             for (const SuperStep &ss : p->steps) {
                 HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi_dev, p->d_scratch,
-                                 p->d_gslabs, st));
+                                 p->d_gslabs, p->seg_scaled, st));
                 HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi_dev, p->d_scratch,
-                                 p->d_gslabs, st));
+                                 p->d_gslabs, p->seg_scaled, st));
             }
             HIPCHK(hipEventRecord(e1, st));
             HIPCHK(hipEventSynchronize(e1));
@@ -540,6 +565,21 @@ int b2x_debug_compile_and_emulate(size_t n_pairs, const b2x_pair *pairs, size_t 
         *fallback = cp.fallback ? 1 : 0;
     if (!cp.fallback && arena && psi && sigma)
         emulate_plan_host(cp, arena, psi, sigma, scale);
+    return B2X_OK;
+}
+
+int b2x_debug_compile_and_emulate_gemms(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size_t out_len,
+                                        uint64_t arena_len, const double *arena, const double *in, double *out,
+                                        double scale, const b2x_plan_options *opt, b2x_plan_stats *stats) {
+    CompiledPlan cp;
+    std::string err;
+    int rc = compile_gemm_list(n_gemms, gemms, in_len, out_len, arena_len, opt, cp, err);
+    if (rc != B2X_OK)
+        return fail(rc, err);
+    if (stats)
+        *stats = cp.stats;
+    if (arena && in && out)
+        emulate_plan_host(cp, arena, in, out, scale);
     return B2X_OK;
 }
 

@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void hpsi_wave(const DPart *__restrict__ pa
 // private to a wave and are prefetched one chunk ahead straight into registers.  Row tiles are cut at the
 // row-slice boundaries of the sector, so a segment's rows always cover its tile: only columns (B side)
 // and the k tail need masking, and both are applied to the B registers.
-template <int TMF, int CF, int NW, int KC>
+template <int TMF, int CF, int NW, int KC, bool SB>
 __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GSeg *__restrict__ segs,
                                         const double *__restrict__ arena, const double *__restrict__ psi,
                                         double *__restrict__ scratch, double *__restrict__ slabs) {
@@ -237,6 +237,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     uint32_t akq[NI];    // per DMA instruction: k (rowmaj: first k of the granule; kmaj: k of the granule)
     uint32_t boff[CF];   // clamped column * b_sc
     uint32_t colmask = 0, akmax = 0, bkmax = 0, astep = 1;
+    double salpha = 1.0; // SB (single-GEMM lists): per-segment factor, folded into the B fragments
     bool s_kmaj = false, cols_full = false;
 #pragma unroll
     for (int j = 0; j < NI; j++)
@@ -248,6 +249,8 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         s_kmaj = (S.a_sk != 1);
         cols_full = (S.tc0 == 0 && S.nc >= item.cols);
         astep = (uint32_t)S.a_sk;
+        if (SB)
+            salpha = S.alpha;
         akmax = (uint32_t)(S.K - 1) * astep, bkmax = (uint32_t)(S.K - 1) * (uint32_t)S.b_sk;
 #pragma unroll
         for (int j = 0; j < NI; j++) {
@@ -311,7 +314,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         for (int q = 0; q < CF; q++)
 #pragma unroll
             for (int s = 0; s < KS; s++)
-                bcur[q][s] = (!bmasked || ((bmask >> (q * KS + s)) & 1)) ? bnxt[q][s] : 0.0;
+                bcur[q][s] = (!bmasked || ((bmask >> (q * KS + s)) & 1)) ? (SB ? bnxt[q][s] * salpha : bnxt[q][s]) : 0.0;
     };
     // the MFMA block: all TMF x CF fragments, branch-free
     // Pin the issue order inside the MFMA block: LDS reads run LEAD fragments ahead of the MFMAs that consume
@@ -408,7 +411,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
 
 // One launch per stage: every workgroup picks the body specialised for its item's tile height (64-row units), so
 // tiles of all heights share a grid (no per-variant launch tails) and one LDS allocation.
-template <int CF, int NW, int KC>
+template <int CF, int NW, int KC, bool SB>
 __global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
                                                          const double *__restrict__ arena,
                                                          const double *__restrict__ psi, double *__restrict__ scratch,
@@ -417,13 +420,13 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__
     const GItem item = items[blockIdx.x];
     const int v = (item.rows - 1) >> 6;
     if (v == 0)
-        gg_body<4, CF, NW, KC>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<4, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
     else if (v == 1)
-        gg_body<8, CF, NW, KC>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<8, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
     else if (v == 2)
-        gg_body<12, CF, NW, KC>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<12, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
     else
-        gg_body<16, CF, NW, KC>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<16, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
 }
 
 // psi'[tile] += scale * sum_i slab_i[tile]   (fixed order i = 0..n_items-1)
@@ -614,14 +617,18 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
 
 // items of all tile-height variants in one grid: v_begin[0] .. v_begin[kGGVariants]
 hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_begin, const double *arena,
-                     const double *psi, double *scratch, double *slabs, hipStream_t st) {
+                     const double *psi, double *scratch, double *slabs, bool seg_scaled, hipStream_t st) {
     const uint32_t n = v_begin[kGGVariants] - v_begin[0];
     if (n == 0)
         return hipSuccess;
     // chunk depth 16: a 32-deep chunk halves the barriers (+2 % on uniform 1024^3 pairs) but pads every K to 32 and
     // spills at 256 VGPRs (-2 % on the M=4000 plan)
-    hipLaunchKernelGGL((gg_kernel<1, kGGTileN / 16, 16>), dim3(n), dim3(kGGTileN * 4), 0, st, segs, items + v_begin[0],
-                       arena, psi, scratch, slabs);
+    if (seg_scaled)
+        hipLaunchKernelGGL((gg_kernel<1, kGGTileN / 16, 16, true>), dim3(n), dim3(kGGTileN * 4), 0, st, segs,
+                           items + v_begin[0], arena, psi, scratch, slabs);
+    else
+        hipLaunchKernelGGL((gg_kernel<1, kGGTileN / 16, 16, false>), dim3(n), dim3(kGGTileN * 4), 0, st, segs,
+                           items + v_begin[0], arena, psi, scratch, slabs);
     return hipGetLastError();
 }
 

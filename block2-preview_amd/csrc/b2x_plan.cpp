@@ -53,6 +53,72 @@ std::vector<int> unit_cuts(int total) {
     return cuts;
 }
 
+// Sort the output windows and merge overlapping ones into disjoint components (sectors of the output vector with a
+// common leading dimension).  `fallback` is set when the windows cannot be laid on a common grid.
+std::vector<Component> build_components(std::vector<Window> &win, bool &fallback, std::string &reason) {
+    std::stable_sort(win.begin(), win.end(), [](const Window &a, const Window &b) { return a.off < b.off; });
+    std::vector<Component> comps;
+    size_t i = 0;
+    while (i < win.size()) {
+        uint64_t end = win[i].off + (uint64_t)(win[i].m - 1) * win[i].ld + win[i].n;
+        size_t j = i + 1;
+        while (j < win.size() && win[j].off < end) {
+            end = std::max(end, win[j].off + (uint64_t)(win[j].m - 1) * win[j].ld + win[j].n);
+            j++;
+        }
+        Component c;
+        c.base = win[i].off, c.w_begin = (uint32_t)i, c.w_end = (uint32_t)j;
+        // a single-row window may carry any ld; take ld from a multi-row window if there is one
+        int ld = 0;
+        for (size_t k = i; k < j; k++)
+            if (win[k].m > 1) {
+                if (ld == 0)
+                    ld = win[k].ld;
+                else if (ld != win[k].ld) {
+                    fallback = true;
+                    reason = "overlapping output windows with different leading dimensions";
+                }
+            }
+        if (ld == 0) {
+            ld = 1;
+            for (size_t k = i; k < j; k++)
+                ld = std::max(ld, (int)(win[k].off - c.base) + win[k].n);
+        }
+        c.ld = ld, c.rows = 0, c.cols = 0;
+        // column alignment: find shift c0 so that no window wraps around a row
+        int c0 = 0;
+        for (int attempt = 0; attempt < 2 && !fallback; attempt++) {
+            bool ok = true;
+            for (size_t k = i; k < j && ok; k++) {
+                uint64_t rel = win[k].off - c.base + (uint64_t)c0;
+                if ((int)(rel % (uint64_t)ld) + win[k].n > ld)
+                    ok = false, c0 = (int)((uint64_t)ld - (win[k].off - c.base) % (uint64_t)ld) % ld;
+            }
+            if (ok)
+                break;
+            if (attempt == 1) {
+                fallback = true;
+                reason = "output windows do not share a row alignment";
+            }
+        }
+        if ((uint64_t)c0 > c.base) {
+            fallback = true;
+            reason = "output window alignment precedes psi'";
+        }
+        if (!fallback) {
+            c.base -= (uint64_t)c0;
+            for (size_t k = i; k < j; k++) {
+                uint64_t rel = win[k].off - c.base;
+                c.rows = std::max(c.rows, (int)(rel / (uint64_t)ld) + win[k].m);
+                c.cols = std::max(c.cols, (int)(rel % (uint64_t)ld) + win[k].n);
+            }
+        }
+        comps.push_back(c);
+        i = j;
+    }
+    return comps;
+}
+
 } // namespace
 
 int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len, uint64_t arena_len,
@@ -108,68 +174,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     std::vector<Window> win(n_pairs);
     for (size_t i = 0; i < n_pairs; i++)
         win[i] = Window{pairs[i].v_off, pairs[i].m1, pairs[i].n1, pairs[i].ldc1, (uint32_t)i};
-    std::stable_sort(win.begin(), win.end(), [](const Window &a, const Window &b) { return a.off < b.off; });
-    std::vector<Component> comps;
-    {
-        size_t i = 0;
-        while (i < win.size()) {
-            uint64_t end = win[i].off + (uint64_t)(win[i].m - 1) * win[i].ld + win[i].n;
-            size_t j = i + 1;
-            while (j < win.size() && win[j].off < end) {
-                end = std::max(end, win[j].off + (uint64_t)(win[j].m - 1) * win[j].ld + win[j].n);
-                j++;
-            }
-            Component c;
-            c.base = win[i].off, c.w_begin = (uint32_t)i, c.w_end = (uint32_t)j;
-            // a single-row window may carry any ld; take ld from a multi-row window if there is one
-            int ld = 0;
-            for (size_t k = i; k < j; k++)
-                if (win[k].m > 1) {
-                    if (ld == 0)
-                        ld = win[k].ld;
-                    else if (ld != win[k].ld) {
-                        out.fallback = true;
-                        out.fallback_reason = "overlapping output windows with different leading dimensions";
-                    }
-                }
-            if (ld == 0) {
-                ld = 1;
-                for (size_t k = i; k < j; k++)
-                    ld = std::max(ld, (int)(win[k].off - c.base) + win[k].n);
-            }
-            c.ld = ld, c.rows = 0, c.cols = 0;
-            // column alignment: find shift c0 so that no window wraps around a row
-            int c0 = 0;
-            for (int attempt = 0; attempt < 2 && !out.fallback; attempt++) {
-                bool ok = true;
-                for (size_t k = i; k < j && ok; k++) {
-                    uint64_t rel = win[k].off - c.base + (uint64_t)c0;
-                    if ((int)(rel % (uint64_t)ld) + win[k].n > ld)
-                        ok = false, c0 = (int)((uint64_t)ld - (win[k].off - c.base) % (uint64_t)ld) % ld;
-                }
-                if (ok)
-                    break;
-                if (attempt == 1) {
-                    out.fallback = true;
-                    out.fallback_reason = "output windows do not share a row alignment";
-                }
-            }
-            if ((uint64_t)c0 > c.base) {
-                out.fallback = true;
-                out.fallback_reason = "output window alignment precedes psi'";
-            }
-            if (!out.fallback) {
-                c.base -= (uint64_t)c0;
-                for (size_t k = i; k < j; k++) {
-                    uint64_t rel = win[k].off - c.base;
-                    c.rows = std::max(c.rows, (int)(rel / (uint64_t)ld) + win[k].m);
-                    c.cols = std::max(c.cols, (int)(rel % (uint64_t)ld) + win[k].n);
-                }
-            }
-            comps.push_back(c);
-            i = j;
-        }
-    }
+    std::vector<Component> comps = build_components(win, out.fallback, out.fallback_reason);
     st.n_targets = comps.size();
     if (out.fallback)
         return B2X_OK;
@@ -343,7 +348,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             g.b_off = p.y_off + (uint64_t)cc[b] * p.ldb0, g.b_sk = 1, g.b_sc = p.ldb0;
                         else
                             g.b_off = p.y_off + (uint64_t)cc[b], g.b_sk = p.ldb0, g.b_sc = 1;
-                        g.K = p.k0;
+                        g.K = p.k0, g.alpha = 1.0;
                         g.mr = rc[a + 1] - rc[a], g.nc = cc[b + 1] - cc[b];
                         GItem it{};
                         it.seg_begin = (uint32_t)out.gsegs.size(), it.seg_end = it.seg_begin + 1;
@@ -404,9 +409,9 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             else
                                 g.a_off = p.z_off + (uint64_t)r_lo * p.lda1, g.a_sr = p.lda1, g.a_sk = 1;
                             g.b_src = 2, g.b_off = cur[q].w_off + (uint64_t)c_lo, g.b_sk = p.n0, g.b_sc = 1;
-                            g.K = p.k1;
+                            g.K = p.k1, g.alpha = 1.0;
                             g.mr = rb - ra, g.nc = cb - ca;
-                            g.tr0 = ra - rc[a], g.tc0 = ca - cc[b];
+                            g.tc0 = ca - cc[b]; // (ra == rc[a]: rows are cut at every window boundary)
                             size_t t = (size_t)a * nct + b;
                             tsegs[t].push_back(g);
                             tcost[t] += (double)round_up(g.mr, 16) * round_up(g.nc, 16) * round_up(g.K, 16) + 65536.0;
@@ -515,6 +520,185 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     }
     st.device_bytes = (out.scratch_elems + out.gslab_elems) * 8 + out.gsegs.size() * sizeof(GSeg) +
                       out.gitems.size() * sizeof(GItem) + out.gtiles.size() * sizeof(DTile) + slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
+    return B2X_OK;
+}
+
+int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size_t out_len, uint64_t arena_len,
+                      const b2x_plan_options *opt, CompiledPlan &out, std::string &err) {
+    out = CompiledPlan();
+    out.seg_scaled = true;
+    b2x_plan_stats &st = out.stats;
+    st.n_pairs = n_gemms, st.psi_len = in_len, st.sigma_len = out_len;
+    std::vector<std::pair<uint64_t, uint64_t>> opext;
+    for (size_t i = 0; i < n_gemms; i++) {
+        const b2x_gemm &g = gemms[i];
+        const std::string id = "gemm " + std::to_string(i);
+        if (g.ta > 1 || g.tb > 1 || g.a_src > 1 || g.b_src > 1) {
+            err = id + ": unsupported transpose / source flags";
+            return B2X_ERR_INVALID;
+        }
+        if (g.m <= 0 || g.n <= 0 || g.k <= 0) {
+            err = id + ": dimensions must be positive";
+            return B2X_ERR_INVALID;
+        }
+        if (g.lda < (g.ta ? g.m : g.k) || g.ldb < (g.tb ? g.k : g.n) || g.ldc < g.n) {
+            err = id + ": leading dimension smaller than row length";
+            return B2X_ERR_INVALID;
+        }
+        uint64_t ea = g.ta ? (uint64_t)(g.k - 1) * g.lda + g.m : (uint64_t)(g.m - 1) * g.lda + g.k;
+        uint64_t eb = g.tb ? (uint64_t)(g.n - 1) * g.ldb + g.k : (uint64_t)(g.k - 1) * g.ldb + g.n;
+        uint64_t ec = (uint64_t)(g.m - 1) * g.ldc + g.n;
+        if (g.a_off + ea > (g.a_src ? (uint64_t)in_len : arena_len) || g.b_off + eb > (g.b_src ? (uint64_t)in_len : arena_len) ||
+            g.c_off + ec > out_len) {
+            err = id + ": operand runs past the end of the input / output vector or the arena";
+            return B2X_ERR_INVALID;
+        }
+        st.macs += (uint64_t)g.m * g.n * g.k;
+        if (!g.a_src)
+            opext.emplace_back(g.a_off, ea);
+        if (!g.b_src)
+            opext.emplace_back(g.b_off, eb);
+    }
+    std::sort(opext.begin(), opext.end());
+    {
+        uint64_t cur_b = 0, cur_e = 0;
+        for (auto &e : opext) {
+            if (e.first >= cur_e) {
+                st.op_elems_unique += cur_e - cur_b;
+                cur_b = e.first, cur_e = e.first + e.second;
+            } else
+                cur_e = std::max(cur_e, e.first + e.second);
+        }
+        st.op_elems_unique += cur_e - cur_b;
+    }
+    if (n_gemms == 0)
+        return B2X_OK;
+    std::vector<Window> win(n_gemms);
+    for (size_t i = 0; i < n_gemms; i++)
+        win[i] = Window{gemms[i].c_off, gemms[i].m, gemms[i].n, gemms[i].ldc, (uint32_t)i};
+    bool bad = false;
+    std::string reason;
+    std::vector<Component> comps = build_components(win, bad, reason);
+    if (bad) { // (there is no atomic fallback for single-GEMM lists)
+        err = reason;
+        return B2X_ERR_INVALID;
+    }
+    st.n_targets = comps.size();
+    const int TN = kGGTileN;
+    const double per_item = opt && opt->item_macs > 0 ? (double)opt->item_macs : 6.0e7;
+    SuperStep ss{};
+    uint64_t slab = 0, gg_macs = 0;
+    for (const Component &c : comps) {
+        std::vector<int> bounds{0, c.rows};
+        for (uint32_t wi = c.w_begin; wi < c.w_end; wi++) {
+            int row0 = (int)((win[wi].off - c.base) / (uint64_t)c.ld);
+            bounds.push_back(row0), bounds.push_back(row0 + win[wi].m);
+        }
+        std::sort(bounds.begin(), bounds.end());
+        bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
+        std::vector<int> rc;
+        for (size_t bi = 0; bi + 1 < bounds.size(); bi++) {
+            std::vector<int> sub = unit_cuts(bounds[bi + 1] - bounds[bi]);
+            for (size_t k = 0; k + 1 < sub.size(); k++)
+                rc.push_back(bounds[bi] + sub[k]);
+        }
+        rc.push_back(c.rows);
+        std::vector<int> cc = balanced_cuts(c.cols, TN);
+        const int nrt = (int)rc.size() - 1, nct = (int)cc.size() - 1;
+        std::vector<std::vector<GSeg>> tsegs((size_t)nrt * nct);
+        std::vector<double> tcost((size_t)nrt * nct, 0.0);
+        // plan order inside a sector (the window array is sorted by offset; replay order = record order)
+        std::vector<uint32_t> members;
+        for (uint32_t wi = c.w_begin; wi < c.w_end; wi++)
+            members.push_back(wi);
+        std::sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) { return win[a].pair < win[b].pair; });
+        for (uint32_t wi : members) {
+            const Window &w = win[wi];
+            const b2x_gemm &p = gemms[w.pair];
+            uint64_t rel = w.off - c.base;
+            int row0 = (int)(rel / (uint64_t)c.ld), col0 = (int)(rel % (uint64_t)c.ld);
+            int a0 = (int)(std::upper_bound(rc.begin(), rc.end(), row0) - rc.begin()) - 1;
+            int b0 = (int)(std::upper_bound(cc.begin(), cc.end(), col0) - cc.begin()) - 1;
+            for (int a = a0; a < nrt && rc[a] < row0 + w.m; a++)
+                for (int b = b0; b < nct && cc[b] < col0 + w.n; b++) {
+                    int ra = std::max(row0, rc[a]), rb = std::min(row0 + w.m, rc[a + 1]);
+                    int ca = std::max(col0, cc[b]), cb = std::min(col0 + w.n, cc[b + 1]);
+                    int r_lo = ra - row0, c_lo = ca - col0;
+                    GSeg g{};
+                    g.a_src = p.a_src, g.b_src = p.b_src;
+                    if (p.ta) // op(A)[r][k] = A[k][r]
+                        g.a_off = p.a_off + (uint64_t)r_lo, g.a_sr = 1, g.a_sk = p.lda;
+                    else
+                        g.a_off = p.a_off + (uint64_t)r_lo * p.lda, g.a_sr = p.lda, g.a_sk = 1;
+                    if (p.tb) // op(B)[k][c] = B[c][k]
+                        g.b_off = p.b_off + (uint64_t)c_lo * p.ldb, g.b_sk = 1, g.b_sc = p.ldb;
+                    else
+                        g.b_off = p.b_off + (uint64_t)c_lo, g.b_sk = p.ldb, g.b_sc = 1;
+                    g.K = p.k, g.alpha = p.alpha;
+                    g.mr = rb - ra, g.nc = cb - ca, g.tc0 = ca - cc[b];
+                    size_t t = (size_t)a * nct + b;
+                    tsegs[t].push_back(g);
+                    tcost[t] += (double)round_up(g.mr, 16) * round_up(g.nc, 16) * round_up(g.K, 16) + 65536.0;
+                    gg_macs += (uint64_t)g.mr * g.nc * g.K;
+                }
+        }
+        for (int a = 0; a < nrt; a++)
+            for (int b = 0; b < nct; b++) {
+                size_t t = (size_t)a * nct + b;
+                if (tsegs[t].empty())
+                    continue;
+                DTile dt{};
+                dt.sigma_off = c.base + (uint64_t)rc[a] * c.ld + cc[b];
+                dt.ld = c.ld, dt.rows = rc[a + 1] - rc[a], dt.cols = cc[b + 1] - cc[b];
+                dt.slab_off = slab;
+                int n_it = std::max(1, (int)std::lround(tcost[t] / per_item));
+                double per = tcost[t] / n_it, acc = 0;
+                int made = 0;
+                uint32_t begin = (uint32_t)out.gsegs.size();
+                for (size_t k = 0; k < tsegs[t].size(); k++) {
+                    const GSeg &g = tsegs[t][k];
+                    out.gsegs.push_back(g);
+                    acc += (double)round_up(g.mr, 16) * round_up(g.nc, 16) * round_up(g.K, 16) + 65536.0;
+                    bool last = k + 1 == tsegs[t].size();
+                    if (last || (acc >= per * (made + 1) && made + 1 < n_it)) {
+                        GItem it{};
+                        it.seg_begin = begin, it.seg_end = (uint32_t)out.gsegs.size();
+                        it.out_off = slab, it.out_ld = dt.cols, it.rows = dt.rows, it.cols = dt.cols;
+                        it.alpha = 1.0, it.out_kind = 0;
+                        out.gitems.push_back(it);
+                        slab += (uint64_t)dt.rows * dt.cols;
+                        begin = it.seg_end;
+                        made++;
+                    }
+                }
+                dt.n_items = made;
+                out.gtiles.push_back(dt);
+            }
+    }
+    auto variant = [](const GItem &x) { return std::min(kGGVariants - 1, (x.rows - 1) / 64); };
+    auto icost = [&](const GItem &x) {
+        uint64_t k = 0;
+        for (uint32_t q = x.seg_begin; q < x.seg_end; q++)
+            k += (uint64_t)round_up(out.gsegs[q].K, 16);
+        return k * (uint64_t)(variant(x) + 1);
+    };
+    std::stable_sort(out.gitems.begin(), out.gitems.end(), [&](const GItem &x, const GItem &y) { return icost(x) > icost(y); });
+    for (int k = 0; k <= kGGVariants; k++)
+        ss.s0_v[k] = 0, ss.s1_v[k] = 0;
+    ss.s1_v[kGGVariants] = (uint32_t)out.gitems.size();
+    ss.tile_begin = 0, ss.tile_end = (uint32_t)out.gtiles.size();
+    for (const GItem &it : out.gitems) {
+        uint64_t tm = 64 * (uint64_t)(variant(it) + 1);
+        for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
+            st.macs_issued += tm * TN * (uint64_t)round_up(out.gsegs[k].K, 16);
+    }
+    out.steps.push_back(ss);
+    out.gslab_elems = slab;
+    st.n_tiles = out.gtiles.size(), st.n_items = out.gitems.size(), st.n_parts = out.gsegs.size();
+    st.macs_executed = gg_macs;
+    st.dominant_class = kNumClasses, st.macs_dominant = gg_macs, st.macs_alg_dominant = gg_macs, st.n_launches = 1;
+    st.device_bytes = out.gslab_elems * 8 + out.gsegs.size() * sizeof(GSeg) + out.gitems.size() * sizeof(GItem) +
+                      out.gtiles.size() * sizeof(DTile);
     return B2X_OK;
 }
 
@@ -637,7 +821,7 @@ void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double
                     for (int k = 0; k < g.K; k++)
                         s += A[g.a_off + (uint64_t)r * g.a_sr + (uint64_t)k * g.a_sk] *
                              B[g.b_off + (uint64_t)k * g.b_sk + (uint64_t)c * g.b_sc];
-                    acc[(size_t)(g.tr0 + r) * it.cols + g.tc0 + c] += s;
+                    acc[(size_t)r * it.cols + g.tc0 + c] += g.alpha * s;
                 }
         }
         double *o = (it.out_kind ? scratch.data() : gslabs.data()) + it.out_off;

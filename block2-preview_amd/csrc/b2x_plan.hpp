@@ -47,16 +47,18 @@ struct DTile {
 static_assert(sizeof(DTile) == 32, "DTile layout");
 
 // ---- two-stage path (large sectors): both stages are plain grouped GEMMs -------------------------
-// One K-segment of a tile's accumulation:  C[tr0:tr0+mr, tc0:tc0+nc] += A(mr x K) * B(K x nc)
+// One K-segment of a tile's accumulation:  C[0:mr, tc0:tc0+nc] += alpha * A(mr x K) * B(K x nc)
+// (row tiles are cut at every window boundary, so a segment always starts at the tile's first row)
 struct GSeg {
     uint64_t a_off, b_off; // element offsets into the buffer selected by a_src / b_src
     int32_t a_sr, a_sk;    // A[r][k] = bufA[a_off + r*a_sr + k*a_sk]
     int32_t b_sk, b_sc;    // B[k][c] = bufB[b_off + k*b_sk + c*b_sc]
     int32_t K;
-    int32_t mr, nc, tr0, tc0;
-    int32_t a_src, b_src; // 0 = operator arena, 1 = psi, 2 = W scratch
-    int32_t pad;          // all fields 32/64-bit so the descriptor is fetched with scalar loads
-};
+    int32_t mr, nc, tc0;
+    int32_t a_src, b_src; // 0 = operator arena, 1 = psi / input vector, 2 = W scratch
+    double alpha;         // applied to the B fragments by the SCALED kernel variant only (single-GEMM lists);
+                          // the H.psi plan keeps 1.0 here and scales once per tile (GItem::alpha)
+};                        // all fields 32/64-bit so the descriptor is fetched with scalar loads
 static_assert(sizeof(GSeg) == 64, "GSeg layout");
 
 struct GItem {
@@ -110,6 +112,7 @@ struct CompiledPlan {
     uint64_t scratch_elems = 0, gslab_elems = 0;
     bool fallback = false; // windows could not be segmented -> generic atomic kernel
     std::string fallback_reason;
+    bool seg_scaled = false; // single-GEMM list: segments carry their own alpha (gg_kernel SCALED variant)
 };
 
 // ---- diagonal build ----------------------------------------------------------------------------------------
@@ -131,6 +134,10 @@ int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, ui
 // returns 0 / B2X_ERR_INVALID (err filled)
 int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len, uint64_t arena_len,
                  const b2x_plan_options *opt, CompiledPlan &out, std::string &err);
+
+// single-GEMM list (b2x_gemm records) -> one super-step of stage-1-shaped items (no stage 0, no W scratch)
+int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size_t out_len, uint64_t arena_len,
+                      const b2x_plan_options *opt, CompiledPlan &out, std::string &err);
 
 // Host emulation of exactly what the device kernels compute from a CompiledPlan (plain loops, no
 // MFMA).  TEST HOOK for the plan compiler only — never reachable from b2x_plan_execute.

@@ -8,6 +8,8 @@
 //   BatchGEMMSeq::rotate         src/core/batch_gemm.hpp:893-902     records one GEMM pair
 //   BatchGEMMSeq::three_rotate   src/core/batch_gemm.hpp:952-1022    records one sliced pair
 //   BatchGEMMSeq::operator()     src/core/batch_gemm.hpp:1563-1684   replays the plan: v += scale * H c
+//   BatchGEMMSeq::multiply / three_rotate_tr_left / three_rotate_tr_right / auto_perform(v)
+//                                src/core/batch_gemm.hpp:887-891, 1025-1109, 1410-1455   single-GEMM lists (noise)
 //   IterativeMatrixFunctions::davidson          src/core/iterative_matrix_functions.hpp:864-1173
 //   IterativeMatrixFunctions::olsen_precondition                     :93-108
 //   EffectiveHamiltonian::{precompute, operator(), eigs, post_precompute}
@@ -190,6 +192,141 @@ struct BatchGEMMSeq {
         check(rc);
         diag_terms.clear(), da_ptr.clear(), db_ptr.clear();
     }
+    // ---- single-GEMM lists (perturbative noise): batch[1]-only records, replayed by auto_perform(v) -----------
+    std::vector<b2x_gemm> gemms;
+    std::vector<const double *> ga_ptr, gb_ptr;
+    std::vector<double *> gc_ptr;
+    size_t gemm_nflop = 0;
+    // one xgemm slot (batch_gemm.hpp:313-320): c(m x n) += alpha op(a) op(b)
+    void push_gemm(int ta, int tb, int m, int n, int k, double alpha, const double *a, int lda, const double *b, int ldb,
+                   double *c, int ldc) {
+        b2x_gemm g{};
+        g.m = m, g.n = n, g.k = k, g.lda = lda, g.ldb = ldb, g.ldc = ldc;
+        g.ta = (uint8_t)ta, g.tb = (uint8_t)tb, g.alpha = alpha;
+        gemms.push_back(g);
+        ga_ptr.push_back(a), gb_ptr.push_back(b), gc_ptr.push_back(c);
+        gemm_nflop += (size_t)m * n * k;
+    }
+    // [c] = scale * op(a) x op(b) + cfactor * [c]      conj & 1 == transpose (BatchGEMM::multiply, :329-337)
+    void multiply(const GMatrix &a, uint8_t conja, const GMatrix &b, uint8_t conjb, const GMatrix &c, double scale,
+                  double cfactor) {
+        if (cfactor != 1.0)
+            throw std::runtime_error("BatchGEMMSeq::multiply: only accumulation (cfactor == 1) is recorded on this path");
+        push_gemm(conja & 1, conjb & 1, c.m, (conjb & 1) ? b.m : b.n, (conjb & 1) ? b.n : b.m, scale, a.data, a.n, b.data,
+                  b.n, c.data, c.n);
+    }
+    // [c] = scale * [a] x op(ket)   with the bra side traced out;  dleft: the row slice (ast, am) of a -> (cst, cm) of c;
+    // !dleft: ket = da x db with one 1 x 1 factor, column slices (batch_gemm.hpp:1025-1064)
+    void three_rotate_tr_left(const GMatrix &a, const GMatrix &c, const GMatrix &bra, bool conj_bra, const GMatrix &ket,
+                              bool conj_ket, const GMatrix &da, bool dconja, const GMatrix &db, bool dconjb, bool dleft,
+                              double scale, uint64_t stride) {
+        if (dleft) {
+            dconja ^= conj_bra, dconjb ^= conj_bra;
+            int am = (dconja ? da.m : da.n) * (dconjb ? db.m : db.n);
+            int cm = (dconja ? da.n : da.m) * (dconjb ? db.n : db.m);
+            uint32_t ast = (uint32_t)(conj_bra ? stride / bra.n : stride % bra.n);
+            uint32_t cst = (uint32_t)(conj_bra ? stride % bra.n : stride / bra.n);
+            multiply(GMatrix(a.data + (size_t)ast * a.n, am, a.n), false, ket, conj_ket ? 1 : 2,
+                     GMatrix(c.data + (size_t)cst * c.n, cm, c.n), scale, 1.0);
+        } else {
+            dconja ^= conj_ket, dconjb ^= conj_ket;
+            uint32_t ast = (uint32_t)(conj_ket ? stride % ket.n : stride / ket.n);
+            uint32_t cst = (uint32_t)(conj_ket ? stride / ket.n : stride % ket.n);
+            const bool a_scalar = da.m == 1 && da.n == 1, b_scalar = db.m == 1 && db.n == 1;
+            if (!a_scalar && !b_scalar)
+                throw std::runtime_error("three_rotate_tr_left: one factor of the delayed operator must be 1 x 1");
+            const GMatrix &big = a_scalar ? db : da;
+            const bool bconj = a_scalar ? dconjb : dconja;
+            const double sc = a_scalar ? *da.data : *db.data;
+            // c[:, cst:] += (scalar * scale) * a[:, ast:] * op(big); the slices keep the parents' leading dimensions
+            push_gemm(0, bconj ? 1 : 0, c.m, bconj ? big.m : big.n, bconj ? big.n : big.m, sc * scale, a.data + ast, a.n,
+                      big.data, big.n, c.data + cst, c.n);
+        }
+    }
+    //  dleft: [c] = scale * [bra] (= [da] x [db]) * [a];  !dleft: [c] = scale * [bra] * [a]  (batch_gemm.hpp:1066-1109)
+    void three_rotate_tr_right(const GMatrix &a, const GMatrix &c, const GMatrix &bra, bool conj_bra, const GMatrix &ket,
+                               bool conj_ket, const GMatrix &da, bool dconja, const GMatrix &db, bool dconjb, bool dleft,
+                               double scale, uint64_t stride) {
+        if (dleft) {
+            dconja ^= conj_bra, dconjb ^= conj_bra;
+            int am = (dconja ? da.m : da.n) * (dconjb ? db.m : db.n);
+            int cm = (dconja ? da.n : da.m) * (dconjb ? db.n : db.m);
+            uint32_t ast = (uint32_t)(conj_bra ? stride / bra.n : stride % bra.n);
+            uint32_t cst = (uint32_t)(conj_bra ? stride % bra.n : stride / bra.n);
+            const bool a_scalar = da.m == 1 && da.n == 1, b_scalar = db.m == 1 && db.n == 1;
+            if (!a_scalar && !b_scalar)
+                throw std::runtime_error("three_rotate_tr_right: one factor of the delayed operator must be 1 x 1");
+            const GMatrix &big = a_scalar ? db : da;
+            const bool bconj = a_scalar ? dconjb : dconja;
+            const double sc = a_scalar ? *da.data : *db.data;
+            multiply(big, bconj ? 3 : 0, GMatrix(a.data + (size_t)ast * a.n, am, a.n), false,
+                     GMatrix(c.data + (size_t)cst * c.n, cm, c.n), scale * sc, 1.0);
+        } else {
+            dconja ^= conj_ket, dconjb ^= conj_ket;
+            int kn = (dconja ? da.m : da.n) * (dconjb ? db.m : db.n);
+            uint32_t ast = (uint32_t)(conj_ket ? stride % ket.n : stride / ket.n);
+            uint32_t cst = (uint32_t)(conj_ket ? stride / ket.n : stride % ket.n);
+            push_gemm(conj_bra ? 1 : 0, 0, c.m, kn, a.m, scale, bra.data, bra.n, a.data + ast, a.n, c.data + cst, c.n);
+        }
+    }
+    // Replay the recorded single-GEMM list: v += records (BatchGEMMSeq::auto_perform(v), Tasked branch), then clear.
+    // Operands inside `in` (the wavefunction) are read from the input vector; all others are operator blocks.
+    void auto_perform(const GMatrix &v, const GMatrix &in = GMatrix(nullptr, 0, 0)) {
+        if (gemms.empty())
+            return;
+        const double *i0 = in.data, *i1 = in.data ? in.data + in.size() : nullptr;
+        std::vector<std::pair<const double *, size_t>> ext;
+        for (size_t i = 0; i < gemms.size(); i++) {
+            b2x_gemm &g = gemms[i];
+            size_t ea = g.ta ? (size_t)(g.k - 1) * g.lda + g.m : (size_t)(g.m - 1) * g.lda + g.k;
+            size_t eb = g.tb ? (size_t)(g.n - 1) * g.ldb + g.k : (size_t)(g.k - 1) * g.ldb + g.n;
+            g.a_src = i0 && ga_ptr[i] >= i0 && ga_ptr[i] < i1, g.b_src = i0 && gb_ptr[i] >= i0 && gb_ptr[i] < i1;
+            if (!g.a_src)
+                ext.emplace_back(ga_ptr[i], ea);
+            if (!g.b_src)
+                ext.emplace_back(gb_ptr[i], eb);
+            if (gc_ptr[i] < v.data || gc_ptr[i] >= v.data + v.size())
+                throw std::runtime_error("BatchGEMMSeq::auto_perform: output pointer outside v");
+            g.c_off = (uint64_t)(gc_ptr[i] - v.data);
+        }
+        std::sort(ext.begin(), ext.end());
+        std::vector<const double *> bases;
+        std::vector<size_t> lens;
+        for (auto &e : ext) {
+            if (!bases.empty() && e.first <= bases.back() + lens.back())
+                lens.back() = std::max(lens.back(), (size_t)(e.first - bases.back()) + e.second);
+            else
+                bases.push_back(e.first), lens.push_back(e.second);
+        }
+        static const double zero = 0.0;
+        if (bases.empty())
+            bases.push_back(&zero), lens.push_back(1);
+        b2x_arena *ar = nullptr;
+        check(b2x_arena_create(&ar, bases.size(), bases.data(), lens.data()));
+        int rc = 0;
+        for (size_t i = 0; i < gemms.size() && rc == 0; i++) {
+            if (gemms[i].a_src)
+                gemms[i].a_off = (uint64_t)(ga_ptr[i] - i0);
+            else
+                rc = b2x_arena_resolve(ar, ga_ptr[i], &gemms[i].a_off);
+            if (gemms[i].b_src)
+                gemms[i].b_off = (uint64_t)(gb_ptr[i] - i0);
+            else if (rc == 0)
+                rc = b2x_arena_resolve(ar, gb_ptr[i], &gemms[i].b_off);
+        }
+        b2x_plan *gp = nullptr;
+        if (rc == 0)
+            rc = b2x_gemm_plan_create(&gp, ar, gemms.size(), gemms.data(), in.size(), v.size(), nullptr);
+        if (rc == 0)
+            rc = b2x_plan_execute(gp, in.data ? in.data : &zero, v.data, 1.0, 0, nullptr);
+        if (gp)
+            b2x_plan_destroy(gp);
+        b2x_arena_destroy(ar);
+        check(rc);
+        cumulative_nflop += gemm_nflop;
+        gemms.clear(), ga_ptr.clear(), gb_ptr.clear(), gc_ptr.clear();
+        gemm_nflop = 0;
+    }
     // upload the operator ranges + compile the device plan (lazily, on first execution)
     void prepare(size_t psi_len_, size_t sigma_len_) {
         if (plan != nullptr)
@@ -244,7 +381,8 @@ struct BatchGEMMSeq {
     void clear() {
         deallocate();
         pairs.clear(), y_ptr.clear(), z_ptr.clear();
-        max_work = 0, nflop = 0;
+        gemms.clear(), ga_ptr.clear(), gb_ptr.clear(), gc_ptr.clear();
+        max_work = 0, nflop = 0, gemm_nflop = 0;
     }
 };
 

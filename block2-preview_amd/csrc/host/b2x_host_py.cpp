@@ -20,6 +20,25 @@ static GMatrix gm(const arr &a) {
 }
 static GMatrix off(uint64_t o, int m, int n) { return GMatrix((double *)0 + o, m, n); }
 
+// operand of a single-GEMM record: a 2-D float64 array (operator block) or (flat float64 array, element offset, m, n)
+// for a block of the wavefunction / the perturbed wavefunctions (row length n at flat + offset)
+static GMatrix gmx(const py::object &o, std::vector<py::object> &keep) {
+    keep.push_back(o);
+    if (py::isinstance<py::tuple>(o)) {
+        py::tuple t = o.cast<py::tuple>();
+        auto flat = t[0].cast<py::array_t<double, py::array::c_style>>();
+        uint64_t off = t[1].cast<uint64_t>();
+        int m = t[2].cast<int>(), n = t[3].cast<int>();
+        if (off + (uint64_t)m * n > (uint64_t)flat.size())
+            throw std::runtime_error("block runs past the end of the flat vector");
+        return GMatrix(const_cast<double *>(flat.data()) + off, m, n);
+    }
+    auto a = o.cast<py::array_t<double, py::array::c_style>>();
+    if (a.ndim() != 2)
+        throw std::runtime_error("expected a 2-D float64 array");
+    return GMatrix(const_cast<double *>(a.data()), (int)a.shape(0), (int)a.shape(1));
+}
+
 struct PySeq : BatchGEMMSeq {
     std::vector<py::object> keep; // operator arrays must outlive the plan upload
     using BatchGEMMSeq::BatchGEMMSeq;
@@ -74,6 +93,59 @@ PYBIND11_MODULE(b2x_host, m) {
                             (double *)0 + q.v_off, q.ldc1);
                  }
              })
+        // ---- single-GEMM lists (perturbative noise) ----
+        .def_property_readonly("n_gemms", [](const PySeq &s) { return s.gemms.size(); })
+        .def("gemm_dims",
+             [](const PySeq &s) { // (ta, tb, m, n, k, lda, ldb, ldc, alpha) per recorded slot
+                 std::vector<std::tuple<int, int, int, int, int, int, int, int, double>> r;
+                 for (const b2x_gemm &g : s.gemms)
+                     r.emplace_back(g.ta, g.tb, g.m, g.n, g.k, g.lda, g.ldb, g.ldc, g.alpha);
+                 return r;
+             })
+        .def("multiply",
+             [](PySeq &s, py::object a, uint8_t conja, py::object b, uint8_t conjb, py::object c, double scale,
+                double cfactor) {
+                 s.multiply(gmx(a, s.keep), conja, gmx(b, s.keep), conjb, gmx(c, s.keep), scale, cfactor);
+             })
+        .def("three_rotate_tr_left",
+             [](PySeq &s, py::object a, py::object c, py::object bra, bool conj_bra, py::object ket, bool conj_ket,
+                py::object da, bool dconja, py::object db, bool dconjb, bool dleft, double scale, uint64_t stride) {
+                 s.three_rotate_tr_left(gmx(a, s.keep), gmx(c, s.keep), gmx(bra, s.keep), conj_bra, gmx(ket, s.keep),
+                                        conj_ket, gmx(da, s.keep), dconja, gmx(db, s.keep), dconjb, dleft, scale, stride);
+             })
+        .def("three_rotate_tr_right",
+             [](PySeq &s, py::object a, py::object c, py::object bra, bool conj_bra, py::object ket, bool conj_ket,
+                py::object da, bool dconja, py::object db, bool dconjb, bool dleft, double scale, uint64_t stride) {
+                 s.three_rotate_tr_right(gmx(a, s.keep), gmx(c, s.keep), gmx(bra, s.keep), conj_bra, gmx(ket, s.keep),
+                                         conj_ket, gmx(da, s.keep), dconja, gmx(db, s.keep), dconjb, dleft, scale, stride);
+             })
+        // load recorded b2x_gemm records: operands resolved against (arena, vin), outputs against vout
+        .def("load_gemms",
+             [](PySeq &s, py::array gemms, arr arena, py::array_t<double, py::array::c_style> vin,
+                py::array_t<double, py::array::c_style> vout) {
+                 if (gemms.itemsize() != (py::ssize_t)sizeof(b2x_gemm))
+                     throw std::runtime_error("gemms: itemsize must equal sizeof(b2x_gemm)");
+                 s.keep.push_back(arena), s.keep.push_back(vin), s.keep.push_back(vout);
+                 const b2x_gemm *g = (const b2x_gemm *)gemms.data();
+                 for (py::ssize_t i = 0; i < gemms.shape(0); i++) {
+                     const b2x_gemm &q = g[i];
+                     s.push_gemm(q.ta, q.tb, q.m, q.n, q.k, q.alpha, (q.a_src ? vin.data() : arena.data()) + q.a_off, q.lda,
+                                 (q.b_src ? vin.data() : arena.data()) + q.b_off, q.ldb, vout.mutable_data() + q.c_off,
+                                 q.ldc);
+                 }
+             })
+        // auto_perform(v [, wavefunction]): v += recorded list; operands inside `wavefunction` use the input vector
+        .def("auto_perform",
+             [](PySeq &s, py::array_t<double, py::array::c_style> v, py::object in) {
+                 GMatrix gin(nullptr, 0, 0);
+                 if (!in.is_none()) {
+                     auto a = in.cast<py::array_t<double, py::array::c_style>>();
+                     gin = GMatrix(const_cast<double *>(a.data()), (int)a.size(), 1);
+                 }
+                 s.auto_perform(GMatrix(v.mutable_data(), (int)v.size(), 1), gin);
+                 s.keep.clear();
+             },
+             py::arg("v"), py::arg("wavefunction") = py::none())
         .def("__call__",
              [](PySeq &s, py::array_t<double, py::array::c_style> c, py::array_t<double, py::array::c_style> v,
                 double scale) {

@@ -22,6 +22,12 @@ DIAG_TERM_DTYPE = np.dtype([("m", "<i4"), ("n", "<i4"), ("a_stride", "<i4"), ("b
                             ("reserved", "<i4"), ("alpha", "<f8"), ("a_off", "<u8"), ("b_off", "<u8"), ("c_off", "<u8")])
 assert DIAG_TERM_DTYPE.itemsize == 56
 
+# numpy view of b2x_gemm (include/b2x.h): one single-GEMM record C += alpha op(A) op(B)
+GEMM_DTYPE = np.dtype([("m", "<i4"), ("n", "<i4"), ("k", "<i4"), ("lda", "<i4"), ("ldb", "<i4"), ("ldc", "<i4"),
+                       ("ta", "u1"), ("tb", "u1"), ("a_src", "u1"), ("b_src", "u1"), ("reserved", "<u4"),
+                       ("alpha", "<f8"), ("a_off", "<u8"), ("b_off", "<u8"), ("c_off", "<u8")])
+assert GEMM_DTYPE.itemsize == 64
+
 F_ARENA, F_PSI, F_SIGMA, F_DIAG, F_PSIOUT = 1, 2, 4, 8, 16
 
 
@@ -145,3 +151,42 @@ def read_arrays(fn):
         out[name] = np.frombuffer(raw, dt, cnt, pos).copy()
         pos += cnt * np.dtype(dt).itemsize
     return out
+
+
+class GemmList:
+    """A captured single-GEMM list (perturbative noise, oracle/ref_dump.cpp capture_pnoise)."""
+    gemms = None
+    arena_len = in_len = out_len = 0
+    macs = 0
+    forward = 0
+    out_offsets = out_lens = None
+    arena = vin = out_ref = None
+
+
+def read_gemm_list(fn):
+    """.pnoise (B2XARR01 with data) or .pnoise_struct.npz (structure only) -> GemmList"""
+    gl = GemmList()
+    if fn.endswith(".npz"):
+        z = np.load(fn, allow_pickle=False)
+        gl.gemms = np.zeros(len(z["m"]), GEMM_DTYPE)
+        for name in GEMM_DTYPE.names:
+            if name != "reserved":
+                gl.gemms[name] = z[name]
+        lens = z["lens"]
+        gl.out_offsets, gl.out_lens = z["out_offsets"].copy(), z["out_lens"].copy()
+    else:
+        d = read_arrays(fn)
+        gl.gemms = np.frombuffer(d["gemms"].tobytes(), GEMM_DTYPE).copy()
+        lens = d["lens"]
+        gl.out_offsets, gl.out_lens = d["out.offsets"], d["out.lens"]
+        gl.arena, gl.vin, gl.out_ref = d.get("arena"), d.get("in"), d.get("out_ref")
+    assert int(lens[0]) == len(gl.gemms)
+    gl.arena_len, gl.in_len, gl.out_len = int(lens[1]), int(lens[2]), int(lens[3])
+    gl.macs, gl.forward = int(lens[5]), int(lens[6])
+    return gl
+
+
+def write_gemm_struct_npz(fn, gl):
+    cols = {n: gl.gemms[n] for n in GEMM_DTYPE.names if n != "reserved"}
+    lens = np.array([len(gl.gemms), gl.arena_len, gl.in_len, gl.out_len, len(gl.out_lens), gl.macs, gl.forward], "<u8")
+    np.savez_compressed(fn, lens=lens, out_offsets=gl.out_offsets, out_lens=gl.out_lens, **cols)

@@ -108,6 +108,43 @@ def scale_plan(pf, f):
     return out
 
 
+def scale_gemm_list(gl, f):
+    """Single-GEMM list with every sector dimension x f (same rule as scale_plan: f*f on whole rows, f on the in-row
+    column offset; operator operands are whole blocks)."""
+    from .planfile import GemmList
+
+    f = int(f)
+    g = gl.gemms
+    i64 = lambda a: a.astype(np.int64)
+    m, n, k = i64(g["m"]), i64(g["n"]), i64(g["k"])
+    # (rows, cols) as stored in memory
+    ar, ac = np.where(g["ta"] == 1, k, m), np.where(g["ta"] == 1, m, k)
+    br, bc = np.where(g["tb"] == 1, n, k), np.where(g["tb"] == 1, k, n)
+    q = g.copy()
+    for nm in ("m", "n", "k", "lda", "ldb", "ldc"):
+        q[nm] = g[nm] * f
+    # input-vector operands (A and B together: they slice the same sectors)
+    ia, ib = np.nonzero(g["a_src"] == 1)[0], np.nonzero(g["b_src"] == 1)[0]
+    off = np.concatenate([i64(g["a_off"])[ia], i64(g["b_off"])[ib]])
+    rows = np.concatenate([ar[ia], br[ib]])
+    cols = np.concatenate([ac[ia], bc[ib]])
+    ld = np.concatenate([i64(g["lda"])[ia], i64(g["ldb"])[ib]])
+    col = _column_offsets(off, rows, cols, ld) if len(off) else np.zeros(0, np.int64)
+    new = f * f * (off - col) + f * col
+    q["a_off"] = (f * f * i64(g["a_off"])).astype(np.uint64)
+    q["b_off"] = (f * f * i64(g["b_off"])).astype(np.uint64)
+    q["a_off"][ia] = new[:len(ia)].astype(np.uint64)
+    q["b_off"][ib] = new[len(ia):].astype(np.uint64)
+    cc = _column_offsets(i64(g["c_off"]), m, n, i64(g["ldc"]))
+    q["c_off"] = (f * f * (i64(g["c_off"]) - cc) + f * cc).astype(np.uint64)
+    out = GemmList()
+    out.gemms = q
+    out.arena_len, out.in_len, out.out_len = gl.arena_len * f * f, gl.in_len * f * f, gl.out_len * f * f
+    out.macs, out.forward = gl.macs * f ** 3, gl.forward
+    out.out_offsets, out.out_lens = gl.out_offsets * (f * f), gl.out_lens * (f * f)
+    return out
+
+
 def shard_pairs(pairs, rank, world):
     """sum-MPO style sharding of one plan: every operator TERM (here: distinct stage-1 left operator
     block z_off, i.e. one left-block operator of the MPO bond) is owned by exactly one rank, as

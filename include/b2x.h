@@ -100,7 +100,7 @@ const char *b2x_version(void);
 int b2x_device_count(int *n);
 int b2x_device_init(int ordinal);                 /* hipSetDevice; fails if no gfx950 device */
 int b2x_device_sync(void);
-int b2x_device_alloc(void **dptr, size_t bytes);  /* hipMalloc  */
+int b2x_device_alloc(void **dptr, size_t bytes);  /* hipMalloc (+64 bytes of slack, see b2x_plan_execute) */
 int b2x_device_free(void *dptr);
 int b2x_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int b2x_memcpy_d2h(void *dst, const void *src, size_t bytes);
@@ -120,7 +120,9 @@ int b2x_arena_destroy(b2x_arena *a);
 int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, const b2x_pair *pairs,
                     size_t psi_len, size_t sigma_len, const b2x_plan_options *opt);
 /* sigma += scale * H * psi.  on_device != 0: psi/sigma are device pointers (no copies);
- * stream: hipStream_t (NULL = default stream).  Asynchronous when on_device != 0. */
+ * stream: hipStream_t (NULL = default stream).  Asynchronous when on_device != 0.
+ * A device psi must be readable for 16 bytes past psi_len (the kernels fetch 16-byte granules; the extra
+ * element is never used): buffers from b2x_device_alloc and any allocator with >= 16-byte slack qualify. */
 int b2x_plan_execute(b2x_plan *p, const double *psi, double *sigma, double scale, int on_device,
                      void *stream);
 int b2x_plan_get_stats(const b2x_plan *p, b2x_plan_stats *st);
@@ -128,6 +130,29 @@ int b2x_plan_get_stats(const b2x_plan *p, b2x_plan_stats *st);
 int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, int n, void *stream,
                          double *avg_ms_main, double *avg_ms_total);
 int b2x_plan_destroy(b2x_plan *p);
+
+/* single-GEMM lists (perturbative noise; partial multiplies) ------------------------------------------------
+ * Replaces: the batch[1]-only lists that BatchGEMMSeq::multiply / three_rotate_tr_left / three_rotate_tr_right
+ * record (src/core/batch_gemm.hpp:887-891, 1025-1109) for OperatorFunctions::tensor_product_multiply with
+ * TraceTypes::Left / Right (src/core/operator_functions.hpp:518-535), replayed by BatchGEMMSeq::auto_perform(v)
+ * (batch_gemm.hpp:1410-1455) inside EffectiveHamiltonian::perturbative_noise (effective_hamiltonian.hpp:252-423).
+ * One record is one xgemm slot (batch_gemm.hpp:289-320):
+ *     C (m x n) += alpha * opA(A)(m x k) * opB(B)(k x n)                beta = 1
+ * A and B each live either in the operator arena or in the INPUT vector (the wavefunction); C is a window of the
+ * OUTPUT vector (the perturbed wavefunctions).  The compiled plan is executed with b2x_plan_execute(plan, input,
+ * output, scale, ...):  output += scale * sum of records. */
+typedef struct b2x_gemm {
+    int32_t m, n, k;
+    int32_t lda, ldb, ldc;
+    uint8_t ta, tb;       /* 0 = no transpose, 1 = transpose */
+    uint8_t a_src, b_src; /* 0 = operator arena, 1 = input vector */
+    uint32_t reserved;
+    double alpha;
+    uint64_t a_off, b_off; /* element offsets into the buffer a_src / b_src selects */
+    uint64_t c_off;        /* element offset into the output vector */
+} b2x_gemm;
+int b2x_gemm_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_gemms, const b2x_gemm *gemms,
+                         size_t in_len, size_t out_len, const b2x_plan_options *opt);
 
 /* diagonal of H_eff (Olsen preconditioner of Davidson) --------------------------------------------------
  * Replaces: the rank-1 products recorded by BatchGEMMSeq / AdvancedGEMM::tensor_product_diagonal and

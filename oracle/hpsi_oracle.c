@@ -23,6 +23,10 @@
  *                        perform_single(stage 0) into thread-local W   (:1630-1632, :359-364, :207-234)
  *                        perform_single(stage 1, scale) into thread-private psi'   (:1633-1635)
  *                      then parallel_reduce tree sum of the private copies (:1507-1523, :1673-1674).
+ *   b2x_oracle_gemm_list  BatchGEMMSeq<double>::auto_perform(v)  src/core/batch_gemm.hpp:1410-1455 (Tasked):
+ *                      the batch[1]-only list recorded by multiply / three_rotate_tr_left / three_rotate_tr_right
+ *                      (:887-891, :1025-1109) for the perturbative noise; per record perform_single (:1431-1434)
+ *                      into a thread-private copy of v, then the same tree reduction.
  */
 #include "../include/b2x.h"
 #include <stdlib.h>
@@ -161,4 +165,38 @@ void b2x_oracle_dense(uint64_t n_pairs, const b2x_pair *pairs, const double *are
         e[j] = 0.0;
     }
     free(e), free(s);
+}
+
+/* out += scale * sum_i alpha_i opA(A_i) opB(B_i) into the windows c_off_i (beta = 1 on every record).
+ * A_i / B_i come from the arena (src 0) or the input vector (src 1).  Returns MACs. */
+uint64_t b2x_oracle_gemm_list(uint64_t n, const b2x_gemm *g, const double *arena, const double *in, double *out,
+                              uint64_t out_len, double scale, int nthreads) {
+    uint64_t macs = 0;
+    if (nthreads < 1)
+        nthreads = 1;
+    double **vs = (double **)calloc((size_t)nthreads, sizeof(double *));
+    vs[0] = out;
+    for (int t = 1; t < nthreads; t++)
+        vs[t] = (double *)calloc(out_len ? out_len : 1, sizeof(double));
+#pragma omp parallel num_threads(nthreads) reduction(+ : macs)
+    {
+        int tid = 0, nt = 1;
+#ifdef _OPENMP
+        tid = omp_get_thread_num(), nt = omp_get_num_threads();
+#endif
+        /* schedule(static): contiguous chunks in record order */
+        uint64_t chunk = (n + (uint64_t)nt - 1) / (uint64_t)nt;
+        uint64_t lo = (uint64_t)tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        for (uint64_t i = lo; i < hi; i++) {
+            const b2x_gemm *p = &g[i];
+            b2x_oracle_gemm(p->ta, p->tb, p->m, p->n, p->k, p->alpha * scale, (p->a_src ? in : arena) + p->a_off, p->lda,
+                            (p->b_src ? in : arena) + p->b_off, p->ldb, 1.0, vs[tid] + p->c_off, p->ldc);
+            macs += (uint64_t)p->m * p->n * p->k;
+        }
+    }
+    tree_reduce(vs, out_len, 0, nthreads);
+    for (int t = 1; t < nthreads; t++)
+        free(vs[t]);
+    free(vs);
+    return macs;
 }

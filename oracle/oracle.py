@@ -25,6 +25,7 @@ def lib():
         build()
         _lib = C.CDLL(_LIB)
         _lib.b2x_oracle_replay.restype = C.c_uint64
+        _lib.b2x_oracle_gemm_list.restype = C.c_uint64
     return _lib
 
 
@@ -51,3 +52,11 @@ def dense(pairs, arena, psi_len, sigma_len):
 def gemm(ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc):
     lib().b2x_oracle_gemm(C.c_int(ta), C.c_int(tb), C.c_int(m), C.c_int(n), C.c_int(k), C.c_double(alpha), _p(a),
                           C.c_int(lda), _p(b), C.c_int(ldb), C.c_double(beta), _p(c), C.c_int(ldc))
+
+
+def gemm_list(gemms, arena, vin, vout, scale=1.0, nthreads=1):
+    """vout += scale * sum of single-GEMM records (in place); returns MACs.  Restates BatchGEMMSeq::auto_perform(v)."""
+    gemms = np.ascontiguousarray(gemms)
+    assert arena.dtype == np.float64 and vin.dtype == np.float64 and vout.dtype == np.float64
+    return int(lib().b2x_oracle_gemm_list(C.c_uint64(len(gemms)), _p(gemms), _p(arena), _p(vin), _p(vout),
+                                          C.c_uint64(vout.size), C.c_double(scale), C.c_int(nthreads)))

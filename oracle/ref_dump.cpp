@@ -15,6 +15,8 @@
  *   dump=<sweep>:<site>[,<sweep>:<site>...]  plans to capture with data
  *   struct=<sweep>:<site>[,...]              plans to capture WITHOUT data (structure only)
  *   eham=<sweep>:<site>[,...]                effective-Hamiltonian level fixtures (infos, tensors, expression)
+ *   pnoise=<sweep>:<site>[,...]              single-GEMM list of the perturbative noise (with data + reference result)
+ *   pnoise_struct=<sweep>:<site>[,...]       the same list without data
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
  */
 #include "block2_core.hpp"
@@ -27,7 +29,7 @@ using namespace block2;
 using namespace std;
 
 struct DumpSpec {
-    set<pair<int, int>> with_data, structure, eham;
+    set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct;
     string prefix;
 };
 
@@ -135,10 +137,51 @@ template <typename S> struct EhamDump {
     }
 };
 
+// TensorFunctions whose partial multiply (virtual, src/core/tensor_functions.hpp:366) keeps a copy of the
+// batch[1] list it recorded, so that the list EffectiveHamiltonian::perturbative_noise replays right afterwards
+// (auto_perform(v), src/dmrg/effective_hamiltonian.hpp:397-402) can be written out next to the reference result.
+template <typename S> struct CapTF : TensorFunctions<S, double> {
+    typedef double FL;
+    mutable vector<b2x_gemm> recs;
+    mutable vector<const double *> pa, pb;
+    mutable vector<double *> pc;
+    mutable const double *out_base = nullptr;
+    mutable size_t out_len = 0;
+    CapTF(const shared_ptr<OperatorFunctions<S, FL>> &opf) : TensorFunctions<S, FL>(opf) {}
+    void tensor_product_partial_multiply(
+        const shared_ptr<OpExpr<S>> &expr, const shared_ptr<OpExpr<S>> &xexpr,
+        const shared_ptr<OperatorTensor<S, FL>> &lopt, const shared_ptr<OperatorTensor<S, FL>> &ropt, bool trace_right,
+        const shared_ptr<SparseMatrix<S, FL>> &cmat, const vector<pair<uint8_t, S>> &psubsl,
+        const vector<vector<shared_ptr<typename SparseMatrixInfo<S>::ConnectionInfo>>> &cinfos, const vector<S> &vdqs,
+        const shared_ptr<SparseMatrixGroup<S, FL>> &vmats, int &vidx, int tvidx, bool do_reduce) const override {
+        TensorFunctions<S, FL>::tensor_product_partial_multiply(expr, xexpr, lopt, ropt, trace_right, cmat, psubsl, cinfos,
+                                                                vdqs, vmats, vidx, tvidx, do_reduce);
+        auto b0 = this->opf->seq->batch[0], b1 = this->opf->seq->batch[1];
+        assert(b0->c.size() == 0 && b1->acidxs.size() == 0);
+        size_t n = b1->c.size();
+        assert(b1->gp.size() == n);
+        recs.resize(n), pa.resize(n), pb.resize(n), pc.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            b2x_gemm &g = recs[i];
+            memset(&g, 0, sizeof(g));
+            g.m = b1->m[i], g.n = b1->n[i], g.k = b1->k[i];
+            g.lda = b1->lda[i], g.ldb = b1->ldb[i], g.ldc = b1->ldc[i];
+            g.ta = (b1->ta[i] == CblasTrans || b1->ta[i] == CblasConjTrans);
+            g.tb = (b1->tb[i] == CblasTrans || b1->tb[i] == CblasConjTrans);
+            g.alpha = b1->alpha[i];
+            assert(b1->beta[i] == 1.0 && b1->gp[i] == 1);
+            pa[i] = b1->a[i], pb[i] = b1->b[i], pc[i] = b1->c[i];
+        }
+        out_base = vmats->data, out_len = vmats->total_memory;
+    }
+};
+
 template <typename S> struct Dumper : CallbackKernel {
     typedef double FL;
     DMRG<S, FL, FL> *dmrg = nullptr;
     DumpSpec spec;
+    bool start_forward = true; // DMRG::forward is only written when solve() returns: sweep isw runs forward iff
+                               // (isw even) == start_forward (src/dmrg/sweep_algorithm.hpp:3076-3101)
     mutable vector<string> log;
     mutable map<pair<int, int>, string> pending; // file awaiting psi_out / energy
     void compute(const string &name, int iprint) const override {
@@ -152,6 +195,10 @@ template <typename S> struct Dumper : CallbackKernel {
                 capture(isw, site, wd);
             if (spec.eham.count(key))
                 capture_eham(isw, site);
+        } else if (name == "DMRG::sweep::iter.eff_ham.end") {
+            bool wd = spec.pnoise.count(key), st = spec.pnoise_struct.count(key);
+            if (wd || st)
+                capture_pnoise(isw, site, wd);
         } else if (name == "DMRG::sweep::iter.end") {
             stringstream ss;
             ss.precision(15);
@@ -260,6 +307,84 @@ template <typename S> struct Dumper : CallbackKernel {
         h->post_precompute();
         af.f64("sigma_ref", sigma);
         cerr << "EHAM " << fn.str() << " terms=" << ty.size() << " arena=" << tot << " psi=" << n << endl;
+    }
+    // perturbative noise: run the reference's own EffectiveHamiltonian::perturbative_noise with the capturing
+    // TensorFunctions swapped in, exactly as DMRG::update_two_dot calls it (src/dmrg/sweep_algorithm.hpp:799-802)
+    void capture_pnoise(int isw, int site, bool with_data) const {
+        auto h = dmrg->current_eff_ham;
+        auto cap = make_shared<CapTF<S>>(h->tf->opf);
+        auto old_tf = h->tf;
+        h->tf = cap;
+        const bool forward = (isw % 2 == 0) == start_forward;
+        auto pket = h->perturbative_noise(forward, site, site + 1, FuseTypes::FuseLR, dmrg->me->ket->info,
+                                          dmrg->noise_type, nullptr);
+        h->tf = old_tf;
+        size_t n = cap->recs.size();
+        const double *ket0 = h->ket->data, *ket1 = ket0 + h->ket->total_memory;
+        vector<pair<const double *, size_t>> ext;
+        for (size_t i = 0; i < n; i++) {
+            b2x_gemm &g = cap->recs[i];
+            size_t ea = g.ta ? (size_t)(g.k - 1) * g.lda + g.m : (size_t)(g.m - 1) * g.lda + g.k;
+            size_t eb = g.tb ? (size_t)(g.n - 1) * g.ldb + g.k : (size_t)(g.k - 1) * g.ldb + g.n;
+            g.a_src = cap->pa[i] >= ket0 && cap->pa[i] < ket1, g.b_src = cap->pb[i] >= ket0 && cap->pb[i] < ket1;
+            if (!g.a_src)
+                ext.push_back(make_pair(cap->pa[i], ea));
+            if (!g.b_src)
+                ext.push_back(make_pair(cap->pb[i], eb));
+            assert(cap->pc[i] >= cap->out_base && cap->pc[i] < cap->out_base + cap->out_len);
+            g.c_off = (uint64_t)(cap->pc[i] - cap->out_base);
+        }
+        sort(ext.begin(), ext.end());
+        vector<pair<const double *, size_t>> rg;
+        for (auto &e : ext) {
+            if (!rg.empty() && e.first <= rg.back().first + rg.back().second)
+                rg.back().second = max(rg.back().second, (size_t)(e.first - rg.back().first) + e.second);
+            else
+                rg.push_back(e);
+        }
+        vector<const double *> starts(rg.size());
+        vector<uint64_t> offs(rg.size());
+        uint64_t tot = 0;
+        for (size_t r = 0; r < rg.size(); r++)
+            starts[r] = rg[r].first, offs[r] = tot, tot += rg[r].second;
+        auto resolve = [&](const double *p) -> uint64_t {
+            size_t r = upper_bound(starts.begin(), starts.end(), p) - starts.begin() - 1;
+            return offs[r] + (uint64_t)(p - starts[r]);
+        };
+        uint64_t macs = 0;
+        for (size_t i = 0; i < n; i++) {
+            b2x_gemm &g = cap->recs[i];
+            g.a_off = g.a_src ? (uint64_t)(cap->pa[i] - ket0) : resolve(cap->pa[i]);
+            g.b_off = g.b_src ? (uint64_t)(cap->pb[i] - ket0) : resolve(cap->pb[i]);
+            macs += (uint64_t)g.m * g.n * g.k;
+        }
+        stringstream fn;
+        fn << spec.prefix << ".sw" << isw << ".site" << site << (with_data ? ".pnoise" : ".pnoise_struct");
+        {
+            ArrayFile af(fn.str());
+            af.put("gemms", 4, 1, cap->recs.data(), n * sizeof(b2x_gemm));
+            af.u64("lens", vector<uint64_t>{(uint64_t)n, tot, (uint64_t)h->ket->total_memory, (uint64_t)cap->out_len,
+                                            (uint64_t)pket->n, macs, (uint64_t)forward});
+            vector<uint64_t> po(pket->n), pl(pket->n);
+            for (int j = 0; j < pket->n; j++)
+                po[j] = pket->offsets[j], pl[j] = (*pket)[j]->total_memory;
+            af.u64("out.offsets", po), af.u64("out.lens", pl);
+            if (with_data) {
+                vector<double> arena(tot);
+                for (size_t r = 0; r < rg.size(); r++)
+                    memcpy(arena.data() + offs[r], rg[r].first, rg[r].second * 8);
+                af.f64("arena", arena);
+                af.f64("in", h->ket->data, h->ket->total_memory);
+                af.f64("out_ref", pket->data, pket->total_memory);
+            }
+        }
+        stringstream ss;
+        ss << "PNOISE " << fn.str() << " gemms=" << n << " in=" << h->ket->total_memory << " out=" << cap->out_len
+           << " kets=" << pket->n << " arena=" << tot << " macs=" << macs;
+        log.push_back(ss.str());
+        cerr << ss.str() << endl;
+        pket->deallocate_infos();
+        pket->deallocate();
     }
     void capture(int isw, int site, bool with_data) const {
         auto h = dmrg->current_eff_ham;
@@ -457,12 +582,17 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     auto dumper = make_shared<Dumper<S>>();
     dumper->dmrg = dmrg.get();
     dumper->spec.prefix = prefix;
+    dumper->start_forward = mps->center == 0;
     if (kv.count("dump"))
         dumper->spec.with_data = parse_pairs(kv["dump"]);
     if (kv.count("struct"))
         dumper->spec.structure = parse_pairs(kv["struct"]);
     if (kv.count("eham"))
         dumper->spec.eham = parse_pairs(kv["eham"]);
+    if (kv.count("pnoise"))
+        dumper->spec.pnoise = parse_pairs(kv["pnoise"]);
+    if (kv.count("pnoise_struct"))
+        dumper->spec.pnoise_struct = parse_pairs(kv["pnoise_struct"]);
     callback_() = dumper;
     double tol = kv.count("tol") ? Parsing::to_double(kv["tol"]) : 1E-8;
     Timer t;
