@@ -8,6 +8,8 @@
 //   BatchGEMMSeq::rotate         src/core/batch_gemm.hpp:893-902     records one GEMM pair
 //   BatchGEMMSeq::three_rotate   src/core/batch_gemm.hpp:952-1022    records one sliced pair
 //   BatchGEMMSeq::operator()     src/core/batch_gemm.hpp:1563-1684   replays the plan: v += scale * H c
+//   BatchGEMMSeq::rotate + rotate_perform        environment rotation c = bra^T a ket of operator blocks: the pairs that
+//                                OperatorFunctions::tensor_rotate records in SeqTypes::Auto (operator_functions.hpp:175-210)
 //   BatchGEMMSeq::multiply / three_rotate_tr_left / three_rotate_tr_right / auto_perform(v)
 //                                src/core/batch_gemm.hpp:887-891, 1025-1109, 1410-1455   single-GEMM lists (noise)
 //   IterativeMatrixFunctions::davidson          src/core/iterative_matrix_functions.hpp:864-1173
@@ -191,6 +193,57 @@ struct BatchGEMMSeq {
         b2x_arena_destroy(ar);
         check(rc);
         diag_terms.clear(), da_ptr.clear(), db_ptr.clear();
+    }
+    // Replay recorded rotate() calls whose a / c operands are ABSOLUTE host blocks (environment rotation: a = blocks of
+    // the enlarged operators, c = blocks of the rotated operators; the reference's Auto-mode auto_perform(),
+    // batch_gemm.hpp:1411-1416).  The a blocks are packed into one device vector (the plan's "psi"), the c blocks into
+    // another ("psi'"), bra / ket blocks form the arena; c += result (beta = 1, as recorded), then the list is cleared.
+    void rotate_perform(const std::vector<std::pair<const double *, size_t>> &a_blocks,
+                        const std::vector<std::pair<double *, size_t>> &c_blocks) {
+        if (pairs.empty())
+            return;
+        struct Packed {
+            std::vector<const double *> starts;
+            std::vector<size_t> lens, offs;
+            size_t tot = 0;
+            void build(std::vector<std::pair<const double *, size_t>> r) {
+                std::sort(r.begin(), r.end());
+                for (auto &e : r) {
+                    if (!starts.empty() && e.first < starts.back() + lens.back()) {
+                        if (e.first + e.second > starts.back() + lens.back())
+                            throw std::runtime_error("rotate_perform: partially overlapping blocks");
+                        continue;
+                    }
+                    starts.push_back(e.first), lens.push_back(e.second), offs.push_back(tot), tot += e.second;
+                }
+            }
+            uint64_t resolve(const double *p) const {
+                size_t r = std::upper_bound(starts.begin(), starts.end(), p) - starts.begin();
+                if (r == 0 || p >= starts[r - 1] + lens[r - 1])
+                    throw std::runtime_error("rotate_perform: operand outside the given blocks");
+                return offs[r - 1] + (uint64_t)(p - starts[r - 1]);
+            }
+        } X, V;
+        X.build(a_blocks);
+        {
+            std::vector<std::pair<const double *, size_t>> cb;
+            for (auto &e : c_blocks)
+                cb.emplace_back(e.first, e.second);
+            V.build(cb);
+        }
+        for (b2x_pair &p : pairs) {
+            p.x_off = X.resolve((const double *)0 + p.x_off);
+            p.v_off = V.resolve((const double *)0 + p.v_off);
+        }
+        std::vector<double> x(X.tot), v(V.tot);
+        for (size_t r = 0; r < X.starts.size(); r++)
+            std::copy(X.starts[r], X.starts[r] + X.lens[r], x.begin() + X.offs[r]);
+        for (size_t r = 0; r < V.starts.size(); r++)
+            std::copy(V.starts[r], V.starts[r] + V.lens[r], v.begin() + V.offs[r]);
+        (*this)(GMatrix(x.data(), (int)x.size(), 1), GMatrix(v.data(), (int)v.size(), 1), 1.0);
+        for (size_t r = 0; r < V.starts.size(); r++)
+            std::copy(v.begin() + V.offs[r], v.begin() + V.offs[r] + V.lens[r], const_cast<double *>(V.starts[r]));
+        clear();
     }
     // ---- single-GEMM lists (perturbative noise): batch[1]-only records, replayed by auto_perform(v) -----------
     std::vector<b2x_gemm> gemms;

@@ -352,6 +352,29 @@ template <typename S> struct OperatorFunctions {
     std::shared_ptr<BatchGEMMSeq> seq;
     CG<S> cg;
     explicit OperatorFunctions(const std::shared_ptr<BatchGEMMSeq> &seq) : seq(seq) {}
+    // c[ic] += scale * op(rot_bra[cq]) a[ia] op(rot_ket[cq']) for every sector of c (operator_functions.hpp:175-210):
+    // a is the operator in the enlarged basis (more sectors than c), the MPS tensor blocks are looked up by the bra /
+    // ket labels of the c sector; trans = false: bra^T . a . ket (left blocks), true: bra . a . ket^T (right blocks)
+    void tensor_rotate(const SparseMatrix<S> &a, const SparseMatrix<S> &c, const SparseMatrix<S> &rot_bra,
+                       const SparseMatrix<S> &rot_ket, bool trans, double scale = 1.0) const {
+        scale = scale * a.factor * rot_bra.factor * rot_ket.factor;
+        if (std::fabs(scale) < 1E-20)
+            return;
+        S adq = a.info->delta_quantum, cdq = c.info->delta_quantum;
+        if (adq != cdq || a.info->n < c.info->n)
+            throw std::runtime_error("tensor_rotate: operator infos do not match");
+        for (int ic = 0, ia = 0; ic < c.info->n; ia++, ic++) {
+            while (ia < a.info->n && a.info->quanta[ia] != c.info->quanta[ic])
+                ia++;
+            if (ia >= a.info->n)
+                throw std::runtime_error("tensor_rotate: sector of c missing in a");
+            S cq = c.info->quanta[ic].get_bra(cdq), cqprime = c.info->quanta[ic].get_ket();
+            int ibra = rot_bra.info->find_state(cq), iket = rot_ket.info->find_state(cqprime);
+            if (ibra < 0 || iket < 0)
+                throw std::runtime_error("tensor_rotate: MPS tensor block not found");
+            seq->rotate(a[ia], c[ic], rot_bra[ibra], (uint8_t)((int)!trans | 2), rot_ket[iket], (uint8_t)trans, scale);
+        }
+    }
     // v[iv] += scale * factor * op(a[ia]) c[ic] op(b[ib])^T for every connection of the matching sub-label
     void tensor_product_multiply(uint8_t conj, const SparseMatrix<S> &a, const SparseMatrix<S> &b,
                                  const SparseMatrix<S> &c, const SparseMatrix<S> &v, S opdq, double scale = 1.0) const {
@@ -466,6 +489,25 @@ template <typename S> struct OperatorFunctions {
 template <typename S> struct TensorFunctions {
     std::shared_ptr<OperatorFunctions<S>> opf;
     explicit TensorFunctions(const std::shared_ptr<OperatorFunctions<S>> &opf) : opf(opf) {}
+    // c = mpst_bra^T x a x mpst_ket for every operator of the enlarged block (tensor_functions.hpp:2365-2383);
+    // right_rotate: c = mpst_bra x a x mpst_ket^T (:2385-2403).  Operators absent from a (null) are skipped.  The pairs
+    // are recorded; BatchGEMMSeq::rotate_perform executes them.
+    void rotate(const OperatorTensor<S> &a, const SparseMatrix<S> &mpst_bra, const SparseMatrix<S> &mpst_ket,
+                const OperatorTensor<S> &c, bool right) const {
+        if (a.ops.size() != c.ops.size())
+            throw std::runtime_error("rotate: operator tensors differ in size");
+        for (size_t i = 0; i < a.ops.size(); i++)
+            if (a.ops[i] && c.ops[i])
+                opf->tensor_rotate(*a.ops[i], *c.ops[i], mpst_bra, mpst_ket, right);
+    }
+    void left_rotate(const OperatorTensor<S> &a, const SparseMatrix<S> &mpst_bra, const SparseMatrix<S> &mpst_ket,
+                     const OperatorTensor<S> &c) const {
+        rotate(a, mpst_bra, mpst_ket, c, false);
+    }
+    void right_rotate(const OperatorTensor<S> &a, const SparseMatrix<S> &mpst_bra, const SparseMatrix<S> &mpst_ket,
+                      const OperatorTensor<S> &c) const {
+        rotate(a, mpst_bra, mpst_ket, c, true);
+    }
     // vmat += expr x cmat: walks the sum of terms (the reference fans this out over threads and merges the
     // per-thread plans; the recorded order is the same)
     void tensor_product_multiply(const std::vector<OpTerm> &expr, const OperatorTensor<S> &lopt,

@@ -226,7 +226,69 @@ template <typename S> struct SymEH : SymEHBase {
     }
 };
 
+// Environment rotation from a symbolic-level fixture (oracle/ref_dump.cpp `erot=`): operator infos of the enlarged and
+// of the rotated block, MPS tensor infos, data.  TensorFunctions::left_rotate / right_rotate records the pairs through
+// OperatorFunctions::tensor_rotate; execute = false returns them (offsets relative to x / v / arena, no device needed),
+// execute = true also runs them on the device (BatchGEMMSeq::rotate_perform) and returns the rotated blocks.
+template <typename S> py::tuple sym_rotate(const py::dict &d, bool execute) {
+    typedef SparseMatrixInfo<S> Info;
+    std::map<int, std::shared_ptr<Info>> cache;
+    py::array_t<double> x = py::array_t<double>(py::array::ensure(d["x"]));
+    py::array_t<double> arena = py::array_t<double>(py::array::ensure(d["arena"]));
+    const uint64_t *meta = SymEH<S>::template arr<uint64_t>(d, "meta");
+    const bool right = meta[2] != 0;
+    py::array_t<double> v((py::ssize_t)meta[6]);
+    std::fill(v.mutable_data(), v.mutable_data() + v.size(), 0.0);
+    size_t n;
+    const int64_t *ai = SymEH<S>::template arr<int64_t>(d, "a.info", &n), *ci = SymEH<S>::template arr<int64_t>(d, "c.info"),
+                  *ao = SymEH<S>::template arr<int64_t>(d, "a.off"), *co = SymEH<S>::template arr<int64_t>(d, "c.off");
+    const double *af = SymEH<S>::template arr<double>(d, "a.factor");
+    OperatorTensor<S> a, c;
+    std::vector<std::pair<const double *, size_t>> ab;
+    std::vector<std::pair<double *, size_t>> cb;
+    for (size_t i = 0; i < n; i++) {
+        auto am = std::make_shared<SparseMatrix<S>>(), cm = std::make_shared<SparseMatrix<S>>();
+        am->info = SymEH<S>::info(d, (int)ai[i], cache), cm->info = SymEH<S>::info(d, (int)ci[i], cache);
+        am->factor = af[i], cm->factor = 1.0;
+        am->data = x.mutable_data() + ao[i], cm->data = v.mutable_data() + co[i];
+        am->total_memory = am->info->get_total_memory(), cm->total_memory = cm->info->get_total_memory();
+        a.ops.push_back(am), c.ops.push_back(cm);
+        ab.emplace_back(am->data, am->total_memory), cb.emplace_back(cm->data, cm->total_memory);
+    }
+    const int64_t *mi = SymEH<S>::template arr<int64_t>(d, "mps.info"), *mo = SymEH<S>::template arr<int64_t>(d, "mps.off");
+    const double *mf = SymEH<S>::template arr<double>(d, "mps.factor");
+    SparseMatrix<S> bra, ket;
+    bra.info = SymEH<S>::info(d, (int)mi[0], cache), ket.info = SymEH<S>::info(d, (int)mi[1], cache);
+    bra.data = arena.mutable_data() + mo[0], ket.data = arena.mutable_data() + mo[1];
+    bra.factor = mf[0], ket.factor = mf[1];
+    auto seq = std::make_shared<BatchGEMMSeq>();
+    TensorFunctions<S> tf(std::make_shared<OperatorFunctions<S>>(seq));
+    if (right)
+        tf.right_rotate(a, bra, ket, c);
+    else
+        tf.left_rotate(a, bra, ket, c);
+    std::vector<b2x_pair> p = seq->pairs;
+    for (size_t i = 0; i < p.size(); i++) {
+        p[i].x_off = (uint64_t)(((const double *)0 + p[i].x_off) - x.data());
+        p[i].v_off = (uint64_t)(((const double *)0 + p[i].v_off) - v.data());
+        p[i].y_off = (uint64_t)(seq->y_ptr[i] - arena.data());
+        p[i].z_off = (uint64_t)(seq->z_ptr[i] - arena.data());
+    }
+    py::array_t<uint8_t> pa(p.size() * sizeof(b2x_pair));
+    std::memcpy(pa.mutable_data(), p.data(), p.size() * sizeof(b2x_pair));
+    if (execute)
+        seq->rotate_perform(ab, cb);
+    return py::make_tuple(pa, v);
+}
+
 inline void bind_symbolic(py::module_ &m) {
+    m.def("symbolic_rotate", [](const std::string &sym, const py::dict &d, bool execute) {
+        if (sym == "sz")
+            return sym_rotate<SZ>(d, execute);
+        if (sym == "su2")
+            return sym_rotate<SU2>(d, execute);
+        throw std::runtime_error("symmetry must be 'sz' or 'su2'");
+    }, py::arg("sym"), py::arg("fixture"), py::arg("execute") = false);
     py::class_<SymEHBase, std::shared_ptr<SymEHBase>>(m, "SymbolicEffectiveHamiltonian")
         .def(py::init([](const std::string &sym, const py::dict &d) -> std::shared_ptr<SymEHBase> {
             if (sym == "sz")

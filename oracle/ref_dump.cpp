@@ -17,6 +17,10 @@
  *   eham=<sweep>:<site>[,...]                effective-Hamiltonian level fixtures (infos, tensors, expression)
  *   pnoise=<sweep>:<site>[,...]              single-GEMM list of the perturbative noise (with data + reference result)
  *   pnoise_struct=<sweep>:<site>[,...]       the same list without data
+ *   rot=<sweep>:<center>[,...]               environment rotation (TensorFunctions::left_rotate / right_rotate called
+ *                                            while MovingEnvironment::center == <center>): GEMM-pair plan + data + result
+ *   rot_struct=<sweep>:<center>[,...]        the same plan without data
+ *   erot=<sweep>:<center>[,...]              the rotation at the symbolic level (operator infos, MPS tensor infos, data)
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
  */
 #include "block2_core.hpp"
@@ -29,7 +33,7 @@ using namespace block2;
 using namespace std;
 
 struct DumpSpec {
-    set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct;
+    set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct, rot, rot_struct, erot;
     string prefix;
 };
 
@@ -173,6 +177,155 @@ template <typename S> struct CapTF : TensorFunctions<S, double> {
             pa[i] = b1->a[i], pb[i] = b1->b[i], pc[i] = b1->c[i];
         }
         out_base = vmats->data, out_len = vmats->total_memory;
+    }
+};
+
+// Environment rotation: TensorFunctions::left_rotate / right_rotate
+// (src/core/tensor_functions.hpp:2365-2403) rotate every operator of the enlarged block into the truncated basis,
+// c[op] = bra^T a[op] ket block by block (OperatorFunctions::tensor_rotate, src/core/operator_functions.hpp:175-210).
+// The override lets the reference compute the result, then asks the reference's OWN tensor_rotate to record the same
+// work into a BatchGEMMSeq in SeqTypes::Auto mode (seq->rotate, :202-204) and writes that pair list as a plan file:
+//   psi   := the operator blocks of a  (stage-0 A operands),   arena := the MPS tensor(s) (bra / ket),
+//   sigma := the operator blocks of c  (stage-1 outputs), sigma_ref = what the reference computed.
+template <typename S> struct RotTF : TensorFunctions<S, double> {
+    typedef double FL;
+    DMRG<S, FL, FL> *dmrg = nullptr;
+    const DumpSpec *spec = nullptr;
+    mutable vector<string> *log = nullptr;
+    RotTF(const shared_ptr<OperatorFunctions<S, FL>> &opf) : TensorFunctions<S, FL>(opf) {}
+    void left_rotate(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<SparseMatrix<S, FL>> &mpst_bra,
+                     const shared_ptr<SparseMatrix<S, FL>> &mpst_ket, shared_ptr<OperatorTensor<S, FL>> &c) const override {
+        TensorFunctions<S, FL>::left_rotate(a, mpst_bra, mpst_ket, c);
+        maybe_capture(a, mpst_bra, mpst_ket, c, false);
+    }
+    void right_rotate(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<SparseMatrix<S, FL>> &mpst_bra,
+                      const shared_ptr<SparseMatrix<S, FL>> &mpst_ket, shared_ptr<OperatorTensor<S, FL>> &c) const override {
+        TensorFunctions<S, FL>::right_rotate(a, mpst_bra, mpst_ket, c);
+        maybe_capture(a, mpst_bra, mpst_ket, c, true);
+    }
+    void maybe_capture(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<SparseMatrix<S, FL>> &bra,
+                       const shared_ptr<SparseMatrix<S, FL>> &ket, const shared_ptr<OperatorTensor<S, FL>> &c,
+                       bool right) const {
+        if (dmrg == nullptr || spec == nullptr)
+            return;
+        pair<int, int> key(dmrg->isweep, dmrg->me->center);
+        bool wd = spec->rot.count(key), st = spec->rot_struct.count(key), er = spec->erot.count(key);
+        if (!wd && !st && !er)
+            return;
+        // record with the reference's tensor_rotate into a private Auto-mode sequence (nothing is executed)
+        auto opf_cap = make_shared<OperatorFunctions<S, FL>>(this->opf->cg);
+        opf_cap->seq = make_shared<BatchGEMMSeq<FL>>(0, SeqTypes::Auto);
+        const auto &names = right ? a->rmat->data : a->lmat->data;
+        vector<pair<const double *, size_t>> xr, vr, opr;
+        for (size_t i = 0; i < names.size(); i++)
+            if (names[i]->get_type() != OpTypes::Zero) {
+                auto pa = abs_value(names[i]);
+                auto am = a->ops.at(pa), cm = c->ops.at(pa);
+                opf_cap->tensor_rotate(am, cm, bra, ket, right);
+                xr.push_back(make_pair((const double *)am->data, (size_t)am->total_memory));
+                vr.push_back(make_pair((const double *)cm->data, (size_t)cm->total_memory));
+            }
+        opr.push_back(make_pair((const double *)bra->data, (size_t)bra->total_memory));
+        opr.push_back(make_pair((const double *)ket->data, (size_t)ket->total_memory));
+        auto b0 = opf_cap->seq->batch[0], b1 = opf_cap->seq->batch[1];
+        size_t n = b0->c.size();
+        assert(b1->c.size() == n && b0->acidxs.size() == 0);
+        // sorted, de-duplicated ranges -> packed offsets
+        struct Packed {
+            vector<const double *> starts;
+            vector<uint64_t> offs, lens;
+            uint64_t tot = 0;
+            void build(vector<pair<const double *, size_t>> r) {
+                sort(r.begin(), r.end());
+                r.erase(unique(r.begin(), r.end()), r.end());
+                for (auto &e : r) {
+                    if (!starts.empty() && e.first < starts.back() + lens.back())
+                        continue; // (identical or nested range)
+                    starts.push_back(e.first), offs.push_back(tot), lens.push_back(e.second), tot += e.second;
+                }
+            }
+            uint64_t resolve(const double *p) const {
+                size_t r = upper_bound(starts.begin(), starts.end(), p) - starts.begin() - 1;
+                assert(p >= starts[r] && p < starts[r] + lens[r]);
+                return offs[r] + (uint64_t)(p - starts[r]);
+            }
+            vector<double> gather() const {
+                vector<double> d(tot);
+                for (size_t r = 0; r < starts.size(); r++)
+                    memcpy(d.data() + offs[r], starts[r], lens[r] * 8);
+                return d;
+            }
+        } X, V, A;
+        X.build(xr), V.build(vr), A.build(opr);
+        vector<b2x_pair> pairs(n);
+        uint64_t macs = 0;
+        for (size_t i = 0; i < n; i++) {
+            b2x_pair &p = pairs[i];
+            memset(&p, 0, sizeof(p));
+            p.m0 = b0->m[i], p.n0 = b0->n[i], p.k0 = b0->k[i], p.lda0 = b0->lda[i], p.ldb0 = b0->ldb[i];
+            p.m1 = b1->m[i], p.n1 = b1->n[i], p.k1 = b1->k[i], p.lda1 = b1->lda[i], p.ldc1 = b1->ldc[i];
+            p.ta0 = b0->ta[i] != CblasNoTrans, p.tb0 = (b0->tb[i] == CblasTrans || b0->tb[i] == CblasConjTrans);
+            p.ta1 = (b1->ta[i] == CblasTrans || b1->ta[i] == CblasConjTrans), p.tb1 = b1->tb[i] != CblasNoTrans;
+            p.alpha0 = b0->alpha[i], p.alpha1 = b1->alpha[i];
+            assert(b0->beta[i] == 0.0 && b1->beta[i] == 1.0 && !p.ta0 && !p.tb1);
+            p.x_off = X.resolve(b0->a[i]), p.y_off = A.resolve(b0->b[i]);
+            p.z_off = A.resolve(b1->a[i]), p.v_off = V.resolve(b1->c[i]);
+            macs += (uint64_t)p.m0 * p.n0 * p.k0 + (uint64_t)p.m1 * p.n1 * p.k1;
+        }
+        if (er) { // symbolic-level fixture: what OperatorFunctions::tensor_rotate consumes (infos) and produces
+            stringstream efn;
+            efn << spec->prefix << ".sw" << key.first << ".c" << key.second << (right ? ".rrot" : ".lrot") << ".erot";
+            EhamDump<S> ed(efn.str());
+            ArrayFile &af = ed.af;
+            vector<int64_t> ai, ci, ao, co;
+            vector<double> afac;
+            for (size_t i = 0; i < names.size(); i++)
+                if (names[i]->get_type() != OpTypes::Zero) {
+                    auto pa = abs_value(names[i]);
+                    auto am = a->ops.at(pa), cm = c->ops.at(pa);
+                    ai.push_back(ed.info_id(am->info, false)), ci.push_back(ed.info_id(cm->info, false));
+                    ao.push_back(am->total_memory ? (int64_t)X.resolve(am->data) : 0);
+                    co.push_back(cm->total_memory ? (int64_t)V.resolve(cm->data) : 0);
+                    afac.push_back(am->factor);
+                }
+            af.i64("a.info", ai), af.i64("c.info", ci), af.i64("a.off", ao), af.i64("c.off", co), af.f64("a.factor", afac);
+            af.i64("mps.info", vector<int64_t>{ed.info_id(bra->info, false), ed.info_id(ket->info, false)});
+            af.i64("mps.off", vector<int64_t>{(int64_t)A.resolve(bra->data), (int64_t)A.resolve(ket->data)});
+            af.f64("mps.factor", vector<double>{bra->factor, ket->factor});
+            af.u64("meta", vector<uint64_t>{(uint64_t)key.first, (uint64_t)key.second, (uint64_t)right, (uint64_t)n, macs,
+                                            X.tot, V.tot, A.tot});
+            af.f64("x", X.gather()), af.f64("arena", A.gather()), af.f64("v_ref", V.gather());
+            cerr << "EROT " << efn.str() << " ops=" << ai.size() << endl;
+        }
+        if (!wd && !st)
+            return;
+        b2x_planfile pf;
+        memset(&pf, 0, sizeof(pf));
+        pf.n_pairs = n, pf.psi_len = X.tot, pf.sigma_len = V.tot, pf.arena_len = A.tot;
+        pf.max_work = opf_cap->seq->max_work;
+        vector<uint64_t> ranges;
+        for (size_t r = 0; r < A.starts.size(); r++)
+            ranges.push_back(A.offs[r]), ranges.push_back(A.lens[r]);
+        pf.n_ranges = A.starts.size(), pf.ranges = ranges.data(), pf.pairs = pairs.data();
+        double meta[8] = {(double)key.first, (double)key.second, 0.0, (double)right, 0.0, (double)macs,
+                          (double)dmrg->me->n_sites, (double)names.size()};
+        pf.meta = meta, pf.n_meta = 8;
+        vector<double> arena, psi, sigma;
+        if (wd) {
+            arena = A.gather(), psi = X.gather(), sigma = V.gather();
+            pf.arena = arena.data(), pf.psi = psi.data(), pf.sigma_ref = sigma.data();
+            pf.flags = B2XPF_ARENA | B2XPF_PSI | B2XPF_SIGMA;
+        }
+        stringstream fn;
+        fn << spec->prefix << ".sw" << key.first << ".c" << key.second << (right ? ".rrot" : ".lrot") << (wd ? ".plan" : ".struct");
+        b2x_planfile_write(fn.str().c_str(), &pf);
+        stringstream ss;
+        ss << "ROT " << fn.str() << " pairs=" << n << " ops=" << xr.size() << " x=" << X.tot << " v=" << V.tot
+           << " mps=" << A.tot << " macs=" << macs;
+        if (log)
+            log->push_back(ss.str());
+        cerr << ss.str() << endl;
+        opf_cap->seq->clear();
     }
 };
 
@@ -593,6 +746,17 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
         dumper->spec.pnoise = parse_pairs(kv["pnoise"]);
     if (kv.count("pnoise_struct"))
         dumper->spec.pnoise_struct = parse_pairs(kv["pnoise_struct"]);
+    if (kv.count("rot"))
+        dumper->spec.rot = parse_pairs(kv["rot"]);
+    if (kv.count("rot_struct"))
+        dumper->spec.rot_struct = parse_pairs(kv["rot_struct"]);
+    if (kv.count("erot"))
+        dumper->spec.erot = parse_pairs(kv["erot"]);
+    if (!dumper->spec.rot.empty() || !dumper->spec.rot_struct.empty() || !dumper->spec.erot.empty()) {
+        auto rtf = make_shared<RotTF<S>>(mpo->tf->opf);
+        rtf->dmrg = dmrg.get(), rtf->spec = &dumper->spec, rtf->log = &dumper->log;
+        mpo->tf = rtf; // MovingEnvironment rotates through mpo->tf (src/dmrg/moving_environment.hpp:360)
+    }
     callback_() = dumper;
     double tol = kv.count("tol") ? Parsing::to_double(kv["tol"]) : 1E-8;
     Timer t;

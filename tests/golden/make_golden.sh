@@ -29,3 +29,10 @@ $R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./p_h10sz pnoise=0:5,1:4 iprint=0
 # Cr2/SVP M=250 noise lists, structure only; converted to .pnoise_struct.npz by
 #   python -c "from block2_preview_amd.planfile import *; write_gemm_struct_npz(out, read_gemm_list(in))"
 $R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2m250 pnoise_struct=0:20,1:20,1:10 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
+# environment-rotation fixtures: the GEMM pairs the reference's own tensor_rotate records (Auto mode)
+# for TensorFunctions::left_rotate / right_rotate, the enlarged operators, the MPS tensor and the rotated operators the
+# reference computed (.plan), plus the same step at the symbolic level (.erot: operator infos, MPS tensor infos)
+$R $D/N2.STO3G.FCIDUMP su2 60 3 ./rot_n2su2 rot=0:4,1:4 erot=0:4,1:4 iprint=0
+$R $D/H10.STO6G.R1.8.FCIDUMP sz 40 3 ./rot_h10sz rot=0:5,1:4 erot=0:5 iprint=0
+# Cr2/SVP M=250 rotation structures -> *.rotstruct.npz (write_struct_npz)
+$R $D/CR2.SVP.FCIDUMP su2 250 2 ./rcr2 rot_struct=0:20,1:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
