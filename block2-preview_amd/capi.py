@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-from .planfile import GEMM_DTYPE, PAIR_DTYPE
+from .planfile import GEMM_DTYPE, OUTER_TERM_DTYPE, PAIR_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libb2x.so")
@@ -21,7 +21,7 @@ DECLARED_SYMBOLS = [
     "b2x_arena_create", "b2x_arena_adopt_device", "b2x_arena_resolve", "b2x_arena_len",
     "b2x_arena_device_ptr", "b2x_arena_destroy",
     "b2x_plan_create", "b2x_plan_execute", "b2x_plan_get_stats", "b2x_plan_time_kernel", "b2x_plan_destroy",
-    "b2x_gemm_plan_create",
+    "b2x_gemm_plan_create", "b2x_outer_build",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
     "b2x_vec_multi_dot", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
 ]
@@ -193,6 +193,27 @@ class GemmPlan(Plan):
                                          C.c_size_t(out_len), C.byref(opt)))
         self._h, self._arena = h, arena
         self.psi_len, self.sigma_len = in_len, out_len
+
+
+def outer_build(arena, terms, vin, vout, on_device=False, in_len=None, out_len=None, stream=0):
+    """vout += sum of element-wise block-product terms (blocking: a (x) site operator, operator sums).  Host numpy arrays
+    (copied through the device) or, with on_device, device pointers + explicit lengths."""
+    terms = np.ascontiguousarray(terms, OUTER_TERM_DTYPE)
+    if not on_device:
+        assert vin.dtype == np.float64 and vout.dtype == np.float64
+        in_len, out_len = vin.size, vout.size
+    check(lib().b2x_outer_build(arena._h, C.c_size_t(len(terms)), _ptr(terms), _ptr(vin), C.c_size_t(in_len),
+                                C.c_size_t(out_len), _ptr(vout), C.c_int(1 if on_device else 0), C.c_void_p(int(stream))))
+
+
+def debug_compile_and_emulate_outer(terms, arena, vin, vout):
+    """TEST HOOK: compile an outer-term list into cells / work units and evaluate it with host loops."""
+    terms = np.ascontiguousarray(terms, OUTER_TERM_DTYPE)
+    nw, ne = C.c_uint64(), C.c_uint64()
+    check(lib().b2x_debug_compile_and_emulate_outer(
+        C.c_size_t(len(terms)), _ptr(terms), C.c_size_t(vin.size), C.c_size_t(vout.size), C.c_uint64(arena.size),
+        _ptr(arena), _ptr(vin), _ptr(vout), C.byref(nw), C.byref(ne)))
+    return nw.value, ne.value
 
 
 def debug_compile_and_emulate_gemms(gemms, in_len, out_len, arena, vin, vout, scale=1.0, item_macs=0):

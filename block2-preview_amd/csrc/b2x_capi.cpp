@@ -476,6 +476,62 @@ int b2x_diag_build(const b2x_arena *arena, size_t n_terms, const b2x_diag_term *
     return rc;
 }
 
+int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term *terms, const double *in, size_t in_len,
+                    size_t out_len, double *out, int on_device, void *stream) {
+    if (!arena || !out || (n_terms && !terms) || (in_len && !in))
+        return fail(B2X_ERR_INVALID, "b2x_outer_build: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(B2X_ERR_DEVICE, "b2x_outer_build: no HIP device (this path has no CPU fallback)");
+    std::vector<OWork> work;
+    std::vector<OEntry> entries;
+    std::string err;
+    int rc = compile_outer(n_terms, terms, in_len, out_len, arena->len, work, entries, err);
+    if (rc != B2X_OK)
+        return fail(rc, "b2x_outer_build: " + err);
+    if (work.empty())
+        return B2X_OK;
+    hipStream_t st = (hipStream_t)stream;
+    OWork *dw = nullptr;
+    OEntry *de = nullptr;
+    double *d_in = const_cast<double *>(in), *d_out = out;
+    rc = upload(&dw, work);
+    if (rc == B2X_OK)
+        rc = upload(&de, entries);
+    if (rc == B2X_OK && !on_device) {
+        hipError_t e = hipMalloc((void **)&d_out, out_len * sizeof(double));
+        if (e == hipSuccess)
+            e = hipMemcpy(d_out, out, out_len * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess && in_len) {
+            e = hipMalloc((void **)&d_in, in_len * sizeof(double));
+            if (e == hipSuccess)
+                e = hipMemcpy(d_in, in, in_len * sizeof(double), hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess)
+            rc = fail(B2X_ERR_DEVICE, std::string("b2x_outer_build: ") + hipGetErrorString(e));
+    }
+    if (rc == B2X_OK) {
+        hipError_t e = launch_outer(dw, (uint32_t)work.size(), de, arena->dev, d_in, d_out, st);
+        if (e == hipSuccess)
+            e = hipStreamSynchronize(st); // metadata is freed below
+        if (e == hipSuccess && !on_device)
+            e = hipMemcpy(out, d_out, out_len * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess)
+            rc = fail(B2X_ERR_DEVICE, std::string("b2x_outer_build: ") + hipGetErrorString(e));
+    }
+    if (dw)
+        (void)hipFree(dw);
+    if (de)
+        (void)hipFree(de);
+    if (!on_device) {
+        if (d_out && d_out != out)
+            (void)hipFree(d_out);
+        if (d_in && d_in != in)
+            (void)hipFree(d_in);
+    }
+    return rc;
+}
+
 // ---------------------------------------------------------------------------------- vectors
 static double *g_dot_partial = nullptr, *g_dot_out = nullptr;
 static int dot_scratch() {
@@ -580,6 +636,24 @@ int b2x_debug_compile_and_emulate_gemms(size_t n_gemms, const b2x_gemm *gemms, s
         *stats = cp.stats;
     if (arena && in && out)
         emulate_plan_host(cp, arena, in, out, scale);
+    return B2X_OK;
+}
+
+int b2x_debug_compile_and_emulate_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, size_t out_len,
+                                        uint64_t arena_len, const double *arena, const double *in, double *out,
+                                        uint64_t *n_work, uint64_t *n_entries) {
+    std::vector<OWork> work;
+    std::vector<OEntry> entries;
+    std::string err;
+    int rc = compile_outer(n_terms, terms, in_len, out_len, arena_len, work, entries, err);
+    if (rc != B2X_OK)
+        return fail(rc, err);
+    if (n_work)
+        *n_work = work.size();
+    if (n_entries)
+        *n_entries = entries.size();
+    if (arena && out)
+        emulate_outer_host(work, entries, arena, in, out);
     return B2X_OK;
 }
 

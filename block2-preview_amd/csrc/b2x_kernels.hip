@@ -518,6 +518,34 @@ hipError_t launch_diag(const DiagComp *comps, uint32_t n_comps, const DiagTermD 
     return hipGetLastError();
 }
 
+// out[cell] += sum over the cell's entries of alpha * A[r][c] * B[r][c]: element-wise block products of the blocking step
+// (a (x) scalar site operator, operator sums).  One workgroup per work unit (an element range of one cell); a thread
+// owns elements and walks the entry list in plan order with no window test: deterministic, no atomics.  HBM-bound:
+// every operand element is read once, consecutive lanes read consecutive addresses when the block is not transposed.
+__global__ __launch_bounds__(256) void outer_build_k(const OWork *__restrict__ work, const OEntry *__restrict__ entries,
+                                                      const double *__restrict__ arena, const double *__restrict__ in,
+                                                      double *__restrict__ out) {
+    const OWork W = work[blockIdx.x];
+    for (uint32_t e = W.e_begin + threadIdx.x; e < W.e_end; e += 256) {
+        const uint32_t r = e / (uint32_t)W.cols, c = e - r * (uint32_t)W.cols;
+        double sum = 0.0;
+        for (uint32_t k = W.entry_begin; k < W.entry_end; k++) {
+            const OEntry T = entries[k];
+            const double a = T.a_src == 2 ? 1.0 : (T.a_src ? in : arena)[T.a_off + (uint64_t)r * T.a_rs + (uint64_t)c * T.a_cs];
+            const double b = T.b_src == 2 ? 1.0 : (T.b_src ? in : arena)[T.b_off + (uint64_t)r * T.b_rs + (uint64_t)c * T.b_cs];
+            sum += T.alpha * a * b;
+        }
+        out[W.out_off + (uint64_t)r * W.ld + c] += sum;
+    }
+}
+hipError_t launch_outer(const OWork *work, uint32_t n_work, const OEntry *entries, const double *arena, const double *in,
+                        double *out, hipStream_t st) {
+    if (n_work == 0)
+        return hipSuccess;
+    hipLaunchKernelGGL(outer_build_k, dim3(n_work), dim3(256), 0, st, work, entries, arena, in, out);
+    return hipGetLastError();
+}
+
 // ------------------------------------ vector kernels ------------------------------------------
 __global__ void vec_axpy_k(double a, const double *x, double *y, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)

@@ -702,6 +702,131 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     return B2X_OK;
 }
 
+int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, size_t out_len, uint64_t arena_len,
+                  std::vector<OWork> &work, std::vector<OEntry> &entries, std::string &err) {
+    work.clear(), entries.clear();
+    auto span = [](int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t &lo, int64_t &hi) {
+        // offsets touched by r*rs + c*cs, r < m, c < n (strides may be 0, never negative)
+        lo = 0, hi = (m - 1) * rs + (n - 1) * cs;
+    };
+    for (size_t i = 0; i < n_terms; i++) {
+        const b2x_outer_term &t = terms[i];
+        const std::string id = "outer term " + std::to_string(i);
+        if (t.m <= 0 || t.n <= 0 || t.ldc < t.n || t.a_src > 2 || t.b_src > 2 || t.a_rs < 0 || t.a_cs < 0 || t.b_rs < 0 ||
+            t.b_cs < 0) {
+            err = id + ": bad dimensions, strides or source flags";
+            return B2X_ERR_INVALID;
+        }
+        int64_t lo, hi;
+        span(t.m, t.n, t.a_rs, t.a_cs, lo, hi);
+        if (t.a_src < 2 && t.a_off + (uint64_t)hi >= (t.a_src ? (uint64_t)in_len : arena_len)) {
+            err = id + ": A operand out of range";
+            return B2X_ERR_INVALID;
+        }
+        span(t.m, t.n, t.b_rs, t.b_cs, lo, hi);
+        if (t.b_src < 2 && t.b_off + (uint64_t)hi >= (t.b_src ? (uint64_t)in_len : arena_len)) {
+            err = id + ": B operand out of range";
+            return B2X_ERR_INVALID;
+        }
+        if (t.c_off + (uint64_t)(t.m - 1) * t.ldc + t.n > out_len) {
+            err = id + ": output window out of range";
+            return B2X_ERR_INVALID;
+        }
+    }
+    if (n_terms == 0)
+        return B2X_OK;
+    std::vector<Window> win(n_terms);
+    for (size_t i = 0; i < n_terms; i++)
+        win[i] = Window{terms[i].c_off, terms[i].m, terms[i].n, terms[i].ldc, (uint32_t)i};
+    bool bad = false;
+    std::string reason;
+    std::vector<Component> comps = build_components(win, bad, reason);
+    if (bad) {
+        err = reason;
+        return B2X_ERR_INVALID;
+    }
+    std::vector<int> rb, cb;
+    std::vector<std::vector<uint32_t>> cell_terms;
+    for (const Component &c : comps) {
+        rb.assign({0, c.rows}), cb.assign({0, c.cols});
+        for (uint32_t wi = c.w_begin; wi < c.w_end; wi++) {
+            uint64_t rel = win[wi].off - c.base;
+            int r0 = (int)(rel / (uint64_t)c.ld), c0 = (int)(rel % (uint64_t)c.ld);
+            rb.push_back(r0), rb.push_back(r0 + win[wi].m), cb.push_back(c0), cb.push_back(c0 + win[wi].n);
+        }
+        std::sort(rb.begin(), rb.end()), rb.erase(std::unique(rb.begin(), rb.end()), rb.end());
+        std::sort(cb.begin(), cb.end()), cb.erase(std::unique(cb.begin(), cb.end()), cb.end());
+        const size_t nr = rb.size() - 1, ncl = cb.size() - 1;
+        cell_terms.assign(nr * ncl, std::vector<uint32_t>());
+        // plan order inside a cell
+        std::vector<uint32_t> members;
+        for (uint32_t wi = c.w_begin; wi < c.w_end; wi++)
+            members.push_back(wi);
+        std::sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) { return win[a].pair < win[b].pair; });
+        for (uint32_t wi : members) {
+            uint64_t rel = win[wi].off - c.base;
+            int r0 = (int)(rel / (uint64_t)c.ld), c0 = (int)(rel % (uint64_t)c.ld);
+            size_t a0 = std::lower_bound(rb.begin(), rb.end(), r0) - rb.begin();
+            size_t b0 = std::lower_bound(cb.begin(), cb.end(), c0) - cb.begin();
+            for (size_t a = a0; a < nr && rb[a] < r0 + win[wi].m; a++)
+                for (size_t b = b0; b < ncl && cb[b] < c0 + win[wi].n; b++)
+                    cell_terms[a * ncl + b].push_back(wi);
+        }
+        for (size_t a = 0; a < nr; a++)
+            for (size_t b = 0; b < ncl; b++) {
+                const auto &lst = cell_terms[a * ncl + b];
+                if (lst.empty())
+                    continue;
+                const uint32_t eb = (uint32_t)entries.size();
+                for (uint32_t wi : lst) {
+                    const b2x_outer_term &t = terms[win[wi].pair];
+                    uint64_t rel = win[wi].off - c.base;
+                    int r0 = (int)(rel / (uint64_t)c.ld), c0 = (int)(rel % (uint64_t)c.ld);
+                    const int64_t dr = rb[a] - r0, dc = cb[b] - c0; // cell origin inside the term window
+                    OEntry e{};
+                    e.a_off = t.a_off + (uint64_t)(dr * t.a_rs + dc * t.a_cs);
+                    e.b_off = t.b_off + (uint64_t)(dr * t.b_rs + dc * t.b_cs);
+                    e.alpha = t.alpha, e.a_rs = t.a_rs, e.a_cs = t.a_cs, e.b_rs = t.b_rs, e.b_cs = t.b_cs;
+                    e.a_src = t.a_src, e.b_src = t.b_src;
+                    entries.push_back(e);
+                }
+                OWork w{};
+                w.out_off = c.base + (uint64_t)rb[a] * c.ld + cb[b];
+                w.ld = c.ld, w.rows = rb[a + 1] - rb[a], w.cols = cb[b + 1] - cb[b];
+                w.entry_begin = eb, w.entry_end = (uint32_t)entries.size();
+                const uint64_t ne = (uint64_t)w.rows * w.cols;
+                if (ne > 0xFFFFFFFFull) {
+                    err = "outer cell larger than 2^32 elements";
+                    return B2X_ERR_INVALID;
+                }
+                // chunk so that a unit carries ~kOuterChunk element-term products
+                uint64_t per = std::max<uint64_t>(256, (uint64_t)kOuterChunk * 4 / std::max<size_t>(1, std::min<size_t>(lst.size(), 64)));
+                for (uint64_t e0 = 0; e0 < ne; e0 += per) {
+                    w.e_begin = (uint32_t)e0, w.e_end = (uint32_t)std::min(ne, e0 + per);
+                    work.push_back(w);
+                }
+            }
+    }
+    return B2X_OK;
+}
+
+void emulate_outer_host(const std::vector<OWork> &work, const std::vector<OEntry> &entries, const double *arena,
+                        const double *in, double *out) {
+    static const double one = 1.0;
+    for (const OWork &w : work)
+        for (uint32_t e = w.e_begin; e < w.e_end; e++) {
+            const int r = (int)(e / (uint32_t)w.cols), c = (int)(e % (uint32_t)w.cols);
+            double sum = 0.0;
+            for (uint32_t k = w.entry_begin; k < w.entry_end; k++) {
+                const OEntry &t = entries[k];
+                const double a = t.a_src == 2 ? one : (t.a_src ? in : arena)[t.a_off + (uint64_t)r * t.a_rs + (uint64_t)c * t.a_cs];
+                const double b = t.b_src == 2 ? one : (t.b_src ? in : arena)[t.b_off + (uint64_t)r * t.b_rs + (uint64_t)c * t.b_cs];
+                sum += t.alpha * a * b;
+            }
+            out[w.out_off + (uint64_t)r * w.ld + c] += sum;
+        }
+}
+
 int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,
                  std::vector<DiagComp> &comps, std::vector<DiagTermD> &dterms, std::string &err) {
     comps.clear(), dterms.clear();

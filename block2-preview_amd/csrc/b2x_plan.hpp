@@ -127,6 +127,32 @@ struct DiagComp {
     int32_t ld, rows, cols;
     uint32_t term_begin, term_end;
 };
+// ---- element-wise block products (blocking) ---------------------------------------------------------------------
+// The windows of one output sector are cut along all their row / column boundaries into CELLS; a cell lists the terms
+// that cover it with operand offsets already moved to the cell origin, so the kernel walks a cell's list without any
+// window test.  Work units are element ranges of a cell (<= kOuterChunk elements).
+struct OEntry {
+    uint64_t a_off, b_off;
+    double alpha;
+    int32_t a_rs, a_cs, b_rs, b_cs;
+    int32_t a_src, b_src;
+};
+static_assert(sizeof(OEntry) == 48, "OEntry layout");
+struct OWork {
+    uint64_t out_off; // output offset of the cell's (0, 0)
+    int32_t ld, rows, cols;
+    uint32_t e_begin, e_end;       // element range of the cell handled by this unit
+    uint32_t entry_begin, entry_end;
+    uint32_t pad;
+};
+static_assert(sizeof(OWork) == 40, "OWork layout");
+static const uint32_t kOuterChunk = 16384;
+int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, size_t out_len, uint64_t arena_len,
+                  std::vector<OWork> &work, std::vector<OEntry> &entries, std::string &err);
+// host evaluation of the compiled work list (TEST HOOK)
+void emulate_outer_host(const std::vector<OWork> &work, const std::vector<OEntry> &entries, const double *arena,
+                        const double *in, double *out);
+
 // groups the terms by output sector (overlapping windows), keeping plan order inside a sector
 int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,
                  std::vector<DiagComp> &comps, std::vector<DiagTermD> &dterms, std::string &err);

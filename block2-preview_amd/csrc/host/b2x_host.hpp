@@ -10,6 +10,8 @@
 //   BatchGEMMSeq::operator()     src/core/batch_gemm.hpp:1563-1684   replays the plan: v += scale * H c
 //   BatchGEMMSeq::rotate + rotate_perform        environment rotation c = bra^T a ket of operator blocks: the pairs that
 //                                OperatorFunctions::tensor_rotate records in SeqTypes::Auto (operator_functions.hpp:175-210)
+//   BatchGEMMSeq::tensor_product / iadd + outer_perform   blocking: c = a (x) b block products and operator sums
+//                                src/core/batch_gemm.hpp:872-885, 1130-1136 -> AdvancedGEMM::tensor_product :431-505
 //   BatchGEMMSeq::multiply / three_rotate_tr_left / three_rotate_tr_right / auto_perform(v)
 //                                src/core/batch_gemm.hpp:887-891, 1025-1109, 1410-1455   single-GEMM lists (noise)
 //   IterativeMatrixFunctions::davidson          src/core/iterative_matrix_functions.hpp:864-1173
@@ -245,6 +247,112 @@ struct BatchGEMMSeq {
             std::copy(v.begin() + V.offs[r], v.begin() + V.offs[r] + V.lens[r], const_cast<double *>(V.starts[r]));
         clear();
     }
+    // ---- element-wise block products (blocking of the environments) -----------------------------------------------
+    std::vector<b2x_outer_term> outer_terms;
+    std::vector<const double *> oa_ptr, ob_ptr;
+    std::vector<double *> oc_ptr;
+    // C[r][c] += alpha * A[r*a_rs + c*a_cs] * B[r*b_rs + c*b_cs]; a null operand pointer means the constant 1.0
+    void push_outer(int m, int n, const double *a, int a_rs, int a_cs, const double *b, int b_rs, int b_cs, double *c,
+                    int ldc, double alpha) {
+        b2x_outer_term t{};
+        t.m = m, t.n = n, t.a_rs = a_rs, t.a_cs = a_cs, t.b_rs = b_rs, t.b_cs = b_cs, t.ldc = ldc, t.alpha = alpha;
+        t.a_src = a ? 0 : 2, t.b_src = b ? 0 : 2;
+        outer_terms.push_back(t);
+        oa_ptr.push_back(a), ob_ptr.push_back(b), oc_ptr.push_back(c);
+    }
+    // [c + stride] += scale * op(a) (x) op(b)   (BatchGEMMSeq::tensor_product, batch_gemm.hpp:1130-1136; the window of
+    // c starts `stride` elements after c(0, 0) and keeps c's leading dimension).  conj = transpose (real double).
+    void tensor_product(const GMatrix &a, bool conja, const GMatrix &b, bool conjb, const GMatrix &c, double scale,
+                        uint64_t stride) {
+        double *cw = c.data + stride;
+        const int am = conja ? a.n : a.m, an = conja ? a.m : a.n; // shape of op(a)
+        const int bm = conjb ? b.n : b.m, bn = conjb ? b.m : b.n;
+        const int a_rs = conja ? 1 : a.n, a_cs = conja ? a.n : 1; // op(a)[i][j] = a.data[i*a_rs + j*a_cs]
+        const int b_rs = conjb ? 1 : b.n, b_cs = conjb ? b.n : 1;
+        if (a.m == 1 && a.n == 1)
+            push_outer(bm, bn, b.data, b_rs, b_cs, a.data, 0, 0, cw, c.n, scale);
+        else if (b.m == 1 && b.n == 1)
+            push_outer(am, an, a.data, a_rs, a_cs, b.data, 0, 0, cw, c.n, scale);
+        else // general Kronecker product: one term per element of op(a), the block op(b) scaled by it
+            for (int i = 0; i < am; i++)
+                for (int j = 0; j < an; j++)
+                    push_outer(bm, bn, b.data, b_rs, b_cs, a.data + (size_t)i * a_rs + (size_t)j * a_cs, 0, 0,
+                               cw + (size_t)i * bm * c.n + (size_t)j * bn, c.n, scale);
+    }
+    // [a] += scale * op(b)   (BatchGEMMSeq::iadd, batch_gemm.hpp:872-881; cfactor must be 1 on this path)
+    void iadd(const GMatrix &a, const GMatrix &b, double scale = 1.0, bool conj = false, double cfactor = 1.0) {
+        if (cfactor != 1.0)
+            throw std::runtime_error("BatchGEMMSeq::iadd: only accumulation (cfactor == 1) is recorded on this path");
+        if (!conj)
+            push_outer(1, a.m * a.n, b.data, 0, 1, nullptr, 0, 0, a.data, a.m * a.n, scale);
+        else
+            push_outer(b.n, b.m, b.data, 1, b.n, nullptr, 0, 0, a.data, a.n, scale);
+    }
+    // Execute the recorded block products: operands are absolute host blocks (block operators, site operators), the
+    // outputs lie inside `c_blocks` (the enlarged operators), which are packed into one device vector, accumulated
+    // into and copied back.  Clears the list.
+    void outer_perform(const std::vector<std::pair<double *, size_t>> &c_blocks) {
+        if (outer_terms.empty())
+            return;
+        std::vector<std::pair<const double *, size_t>> ext;
+        for (size_t i = 0; i < outer_terms.size(); i++) {
+            const b2x_outer_term &t = outer_terms[i];
+            if (oa_ptr[i])
+                ext.emplace_back(oa_ptr[i], (size_t)(t.m - 1) * t.a_rs + (size_t)(t.n - 1) * t.a_cs + 1);
+            if (ob_ptr[i])
+                ext.emplace_back(ob_ptr[i], (size_t)(t.m - 1) * t.b_rs + (size_t)(t.n - 1) * t.b_cs + 1);
+        }
+        std::sort(ext.begin(), ext.end());
+        std::vector<const double *> bases;
+        std::vector<size_t> lens;
+        for (auto &e : ext) {
+            if (!bases.empty() && e.first <= bases.back() + lens.back())
+                lens.back() = std::max(lens.back(), (size_t)(e.first - bases.back()) + e.second);
+            else
+                bases.push_back(e.first), lens.push_back(e.second);
+        }
+        static const double zero = 0.0;
+        if (bases.empty())
+            bases.push_back(&zero), lens.push_back(1);
+        // pack the output blocks
+        std::vector<std::pair<double *, size_t>> cb = c_blocks;
+        std::sort(cb.begin(), cb.end());
+        std::vector<size_t> coff(cb.size());
+        size_t ctot = 0;
+        for (size_t r = 0; r < cb.size(); r++)
+            coff[r] = ctot, ctot += cb[r].second;
+        auto cres = [&](double *p) -> uint64_t {
+            size_t r = std::upper_bound(cb.begin(), cb.end(), std::make_pair(p, (size_t)-1)) - cb.begin();
+            if (r == 0 || p >= cb[r - 1].first + cb[r - 1].second)
+                throw std::runtime_error("outer_perform: output outside the given blocks");
+            return coff[r - 1] + (uint64_t)(p - cb[r - 1].first);
+        };
+        b2x_arena *ar = nullptr;
+        check(b2x_arena_create(&ar, bases.size(), bases.data(), lens.data()));
+        int rc = 0;
+        try {
+            for (size_t i = 0; i < outer_terms.size() && rc == 0; i++) {
+                if (oa_ptr[i])
+                    rc = b2x_arena_resolve(ar, oa_ptr[i], &outer_terms[i].a_off);
+                if (ob_ptr[i] && rc == 0)
+                    rc = b2x_arena_resolve(ar, ob_ptr[i], &outer_terms[i].b_off);
+                outer_terms[i].c_off = cres(oc_ptr[i]);
+            }
+        } catch (...) {
+            b2x_arena_destroy(ar);
+            throw;
+        }
+        std::vector<double> v(ctot);
+        for (size_t r = 0; r < cb.size(); r++)
+            std::copy(cb[r].first, cb[r].first + cb[r].second, v.begin() + coff[r]);
+        if (rc == 0)
+            rc = b2x_outer_build(ar, outer_terms.size(), outer_terms.data(), nullptr, 0, v.size(), v.data(), 0, nullptr);
+        b2x_arena_destroy(ar);
+        check(rc);
+        for (size_t r = 0; r < cb.size(); r++)
+            std::copy(v.begin() + coff[r], v.begin() + coff[r] + cb[r].second, cb[r].first);
+        outer_terms.clear(), oa_ptr.clear(), ob_ptr.clear(), oc_ptr.clear();
+    }
     // ---- single-GEMM lists (perturbative noise): batch[1]-only records, replayed by auto_perform(v) -----------
     std::vector<b2x_gemm> gemms;
     std::vector<const double *> ga_ptr, gb_ptr;
@@ -435,6 +543,7 @@ struct BatchGEMMSeq {
         deallocate();
         pairs.clear(), y_ptr.clear(), z_ptr.clear();
         gemms.clear(), ga_ptr.clear(), gb_ptr.clear(), gc_ptr.clear();
+        outer_terms.clear(), oa_ptr.clear(), ob_ptr.clear(), oc_ptr.clear();
         max_work = 0, nflop = 0, gemm_nflop = 0;
     }
 };

@@ -93,6 +93,46 @@ PYBIND11_MODULE(b2x_host, m) {
                             (double *)0 + q.v_off, q.ldc1);
                  }
              })
+        // ---- element-wise block products (blocking) ----
+        .def_property_readonly("n_outer", [](const PySeq &s) { return s.outer_terms.size(); })
+        .def("outer_dims",
+             [](const PySeq &s) { // (m, n, a_rs, a_cs, b_rs, b_cs, ldc, alpha) per recorded term
+                 std::vector<std::tuple<int, int, int, int, int, int, int, double>> r;
+                 for (const b2x_outer_term &t : s.outer_terms)
+                     r.emplace_back(t.m, t.n, t.a_rs, t.a_cs, t.b_rs, t.b_cs, t.ldc, t.alpha);
+                 return r;
+             })
+        .def("tensor_product",
+             [](PySeq &s, py::object a, bool conja, py::object b, bool conjb, py::object c, double scale, uint64_t stride) {
+                 s.tensor_product(gmx(a, s.keep), conja, gmx(b, s.keep), conjb, gmx(c, s.keep), scale, stride);
+             })
+        .def("iadd",
+             [](PySeq &s, py::object a, py::object b, double scale, bool conj, double cfactor) {
+                 s.iadd(gmx(a, s.keep), gmx(b, s.keep), scale, conj, cfactor);
+             },
+             py::arg("a"), py::arg("b"), py::arg("scale") = 1.0, py::arg("conj") = false, py::arg("cfactor") = 1.0)
+        // load recorded b2x_outer_term records: operands resolved against (arena, vin), outputs against vout
+        .def("load_outer",
+             [](PySeq &s, py::array terms, arr arena, py::array_t<double, py::array::c_style> vin,
+                py::array_t<double, py::array::c_style> vout) {
+                 if (terms.itemsize() != (py::ssize_t)sizeof(b2x_outer_term))
+                     throw std::runtime_error("terms: itemsize must equal sizeof(b2x_outer_term)");
+                 s.keep.push_back(arena), s.keep.push_back(vin), s.keep.push_back(vout);
+                 const b2x_outer_term *t = (const b2x_outer_term *)terms.data();
+                 for (py::ssize_t i = 0; i < terms.shape(0); i++) {
+                     const b2x_outer_term &q = t[i];
+                     const double *a = q.a_src == 2 ? nullptr : (q.a_src ? vin.data() : arena.data()) + q.a_off;
+                     const double *b = q.b_src == 2 ? nullptr : (q.b_src ? vin.data() : arena.data()) + q.b_off;
+                     s.push_outer(q.m, q.n, a, q.a_rs, q.a_cs, b, q.b_rs, q.b_cs, vout.mutable_data() + q.c_off, q.ldc,
+                                  q.alpha);
+                 }
+             })
+        // outer_perform(v): v (flat vector holding every output block) += recorded block products
+        .def("outer_perform",
+             [](PySeq &s, py::array_t<double, py::array::c_style> v) {
+                 s.outer_perform({{v.mutable_data(), (size_t)v.size()}});
+                 s.keep.clear();
+             })
         // ---- single-GEMM lists (perturbative noise) ----
         .def_property_readonly("n_gemms", [](const PySeq &s) { return s.gemms.size(); })
         .def("gemm_dims",

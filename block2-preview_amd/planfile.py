@@ -28,6 +28,12 @@ GEMM_DTYPE = np.dtype([("m", "<i4"), ("n", "<i4"), ("k", "<i4"), ("lda", "<i4"),
                        ("alpha", "<f8"), ("a_off", "<u8"), ("b_off", "<u8"), ("c_off", "<u8")])
 assert GEMM_DTYPE.itemsize == 64
 
+# numpy view of b2x_outer_term (include/b2x.h): C[r][c] += alpha * A[a_off + r*a_rs + c*a_cs] * B[b_off + r*b_rs + c*b_cs]
+OUTER_TERM_DTYPE = np.dtype([("m", "<i4"), ("n", "<i4"), ("a_rs", "<i4"), ("a_cs", "<i4"), ("b_rs", "<i4"), ("b_cs", "<i4"),
+                             ("ldc", "<i4"), ("a_src", "u1"), ("b_src", "u1"), ("reserved", "u1", 2), ("alpha", "<f8"),
+                             ("a_off", "<u8"), ("b_off", "<u8"), ("c_off", "<u8")])
+assert OUTER_TERM_DTYPE.itemsize == 64
+
 F_ARENA, F_PSI, F_SIGMA, F_DIAG, F_PSIOUT = 1, 2, 4, 8, 16
 
 

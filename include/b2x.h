@@ -172,6 +172,31 @@ typedef struct b2x_diag_term {
 int b2x_diag_build(const b2x_arena *arena, size_t n_terms, const b2x_diag_term *terms, size_t diag_len, double *diag,
                    int on_device, void *stream);
 
+/* element-wise block products (blocking of the environments; operator sums) ----------------------------------
+ * Replaces: the k = 1 GEMM groups AdvancedGEMM::tensor_product records for c = a (x) b when one factor is 1 x 1 (the
+ * site operators of a quantum-chemistry MPO) or block by block otherwise (src/core/batch_gemm.hpp:431-505, executed by
+ * GMatrixFunctions::tensor_product, src/core/matrix_functions.hpp:1117-1177, under OperatorFunctions::tensor_product,
+ * src/core/operator_functions.hpp:672-711 and TensorFunctions::left_contract / right_contract,
+ * src/core/tensor_functions.hpp:2842-2885), and BatchGEMM::iadd (batch_gemm.hpp:313-317; OperatorFunctions::iadd,
+ * operator_functions.hpp:126-174).  One term:
+ *     C[r][c] += alpha * A[a_off + r*a_rs + c*a_cs] * B[b_off + r*b_rs + c*b_cs]        r < m, c < n
+ * where C is a window (c_off, ldc) of the OUTPUT vector (the enlarged operators).  A scalar factor has rs = cs = 0, a
+ * transposed block swaps rs and cs.  Sources: 0 = operator arena, 1 = INPUT vector, 2 = the constant 1.0. */
+typedef struct b2x_outer_term {
+    int32_t m, n;
+    int32_t a_rs, a_cs;
+    int32_t b_rs, b_cs;
+    int32_t ldc;
+    uint8_t a_src, b_src;
+    uint8_t reserved[2];
+    double alpha;
+    uint64_t a_off, b_off;
+    uint64_t c_off;
+} b2x_outer_term;
+/* out += sum of terms.  on_device != 0: in / out are device pointers.  Deterministic (no atomics). */
+int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term *terms, const double *in, size_t in_len,
+                    size_t out_len, double *out, int on_device, void *stream);
+
 /* device-resident vector algebra for Davidson (all pointers are device pointers) ------------ */
 int b2x_vec_dot(const double *x, const double *y, size_t n, double *host_result, void *stream);
 int b2x_vec_axpy(double a, const double *x, double *y, size_t n, void *stream);   /* y += a x */

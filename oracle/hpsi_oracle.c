@@ -27,6 +27,10 @@
  *                      the batch[1]-only list recorded by multiply / three_rotate_tr_left / three_rotate_tr_right
  *                      (:887-891, :1025-1109) for the perturbative noise; per record perform_single (:1431-1434)
  *                      into a thread-private copy of v, then the same tree reduction.
+ *   b2x_oracle_outer   GMatrixFunctions<double>::tensor_product   src/core/matrix_functions.hpp:1117-1177 (what
+ *                      OperatorFunctions::tensor_product runs in Tasked mode, operator_functions.hpp:706-709) in the
+ *                      row-wise k = 1 form AdvancedGEMM::tensor_product records it (src/core/batch_gemm.hpp:431-505):
+ *                      c[r][:] += alpha * a-row * scalar, and GMatrixFunctions::iadd (:229-262).
  */
 #include "../include/b2x.h"
 #include <stdlib.h>
@@ -199,4 +203,21 @@ uint64_t b2x_oracle_gemm_list(uint64_t n, const b2x_gemm *g, const double *arena
         free(vs[t]);
     free(vs);
     return macs;
+}
+
+/* out[c_off + r*ldc + c] += alpha * A[a_off + r*a_rs + c*a_cs] * B[b_off + r*b_rs + c*b_cs] for every term, in order */
+void b2x_oracle_outer(uint64_t n, const b2x_outer_term *t, const double *arena, const double *in, double *out) {
+    static const double one = 1.0;
+    for (uint64_t i = 0; i < n; i++) {
+        const b2x_outer_term *p = &t[i];
+        const double *A = p->a_src == 2 ? &one : (p->a_src ? in : arena) + p->a_off;
+        const double *B = p->b_src == 2 ? &one : (p->b_src ? in : arena) + p->b_off;
+        const size_t ars = p->a_src == 2 ? 0 : (size_t)p->a_rs, acs = p->a_src == 2 ? 0 : (size_t)p->a_cs;
+        const size_t brs = p->b_src == 2 ? 0 : (size_t)p->b_rs, bcs = p->b_src == 2 ? 0 : (size_t)p->b_cs;
+        for (int r = 0; r < p->m; r++) {
+            double *c = out + p->c_off + (size_t)r * p->ldc;
+            for (int j = 0; j < p->n; j++)
+                c[j] += p->alpha * A[r * ars + j * acs] * B[r * brs + j * bcs];
+        }
+    }
 }

@@ -60,3 +60,10 @@ def gemm_list(gemms, arena, vin, vout, scale=1.0, nthreads=1):
     assert arena.dtype == np.float64 and vin.dtype == np.float64 and vout.dtype == np.float64
     return int(lib().b2x_oracle_gemm_list(C.c_uint64(len(gemms)), _p(gemms), _p(arena), _p(vin), _p(vout),
                                           C.c_uint64(vout.size), C.c_double(scale), C.c_int(nthreads)))
+
+
+def outer(terms, arena, vin, vout):
+    """vout += element-wise block-product terms (in place).  Restates GMatrixFunctions::tensor_product / iadd."""
+    terms = np.ascontiguousarray(terms)
+    assert terms.dtype.itemsize == 64 and arena.dtype == np.float64 and vin.dtype == np.float64 and vout.dtype == np.float64
+    lib().b2x_oracle_outer(C.c_uint64(len(terms)), _p(terms), _p(arena), _p(vin), _p(vout))

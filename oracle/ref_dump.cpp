@@ -21,6 +21,9 @@
  *                                            while MovingEnvironment::center == <center>): GEMM-pair plan + data + result
  *   rot_struct=<sweep>:<center>[,...]        the same plan without data
  *   erot=<sweep>:<center>[,...]              the rotation at the symbolic level (operator infos, MPS tensor infos, data)
+ *   blk=<sweep>:<center>[,...]               blocking (TensorFunctions::left_contract / right_contract called while
+ *                                            center == <center>): element-wise block-product terms + data + result
+ *   blk_struct=<sweep>:<center>[,...]        the same terms without data
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
  */
 #include "block2_core.hpp"
@@ -33,7 +36,7 @@ using namespace block2;
 using namespace std;
 
 struct DumpSpec {
-    set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct, rot, rot_struct, erot;
+    set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct, rot, rot_struct, erot, blk, blk_struct;
     string prefix;
 };
 
@@ -202,6 +205,199 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
                       const shared_ptr<SparseMatrix<S, FL>> &mpst_ket, shared_ptr<OperatorTensor<S, FL>> &c) const override {
         TensorFunctions<S, FL>::right_rotate(a, mpst_bra, mpst_ket, c);
         maybe_capture(a, mpst_bra, mpst_ket, c, true);
+    }
+    // ---- blocking: c = a (x) b for every operator of the enlarged block (tensor_functions.hpp:2842-2885, 2941-2983)
+    void left_contract(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<OperatorTensor<S, FL>> &b,
+                       shared_ptr<OperatorTensor<S, FL>> &c, const shared_ptr<Symbolic<S>> &cexprs = nullptr,
+                       OpNamesSet delayed = OpNamesSet()) const override {
+        TensorFunctions<S, FL>::left_contract(a, b, c, cexprs, delayed);
+        capture_blocking(a, b, c, cexprs, delayed, false);
+    }
+    void right_contract(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<OperatorTensor<S, FL>> &b,
+                        shared_ptr<OperatorTensor<S, FL>> &c, const shared_ptr<Symbolic<S>> &cexprs = nullptr,
+                        OpNamesSet delayed = OpNamesSet()) const override {
+        TensorFunctions<S, FL>::right_contract(a, b, c, cexprs, delayed);
+        capture_blocking(a, b, c, cexprs, delayed, true);
+    }
+    struct Packed2 {
+        vector<const double *> starts;
+        vector<uint64_t> offs, lens;
+        uint64_t tot = 0;
+        void build(vector<pair<const double *, size_t>> r) {
+            sort(r.begin(), r.end());
+            for (auto &e : r) {
+                if (e.second == 0 || (!starts.empty() && e.first < starts.back() + lens.back()))
+                    continue;
+                starts.push_back(e.first), offs.push_back(tot), lens.push_back(e.second), tot += e.second;
+            }
+        }
+        bool resolve(const double *p, uint64_t &off) const {
+            size_t r = upper_bound(starts.begin(), starts.end(), p) - starts.begin();
+            if (r == 0 || p >= starts[r - 1] + lens[r - 1])
+                return false;
+            off = offs[r - 1] + (uint64_t)(p - starts[r - 1]);
+            return true;
+        }
+        vector<double> gather() const {
+            vector<double> d(tot);
+            for (size_t r = 0; r < starts.size(); r++)
+                memcpy(d.data() + offs[r], starts[r], lens[r] * 8);
+            return d;
+        }
+    };
+    // The reference's own TensorFunctions::tensor_product (public) is asked to record the contraction of every
+    // operator into a private Auto-mode sequence: batch[1] then holds the k = 1 GEMM groups of
+    // AdvancedGEMM::tensor_product (src/core/batch_gemm.hpp:431-505).  Runs of group members with constant pointer
+    // steps are written as one 2-D term  C[r][c] += alpha * A[r*a_rs + c*a_cs] * B[0]  (a mechanical re-grouping).
+    void capture_blocking(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<OperatorTensor<S, FL>> &b,
+                          const shared_ptr<OperatorTensor<S, FL>> &c, const shared_ptr<Symbolic<S>> &cexprs,
+                          OpNamesSet delayed, bool right) const {
+        if (dmrg == nullptr || spec == nullptr || a == nullptr || !delayed.empty())
+            return;
+        pair<int, int> key(dmrg->isweep, dmrg->me->center);
+        const bool with_data = spec->blk.count(key);
+        if (!with_data && !spec->blk_struct.count(key))
+            return;
+        {
+            static set<string> done; // first call per (sweep, center, side) only
+            stringstream id;
+            id << key.first << ":" << key.second << ":" << right;
+            if (!done.insert(id.str()).second)
+                return;
+        }
+        auto opf_cap = make_shared<OperatorFunctions<S, FL>>(this->opf->cg);
+        opf_cap->seq = make_shared<BatchGEMMSeq<FL>>(0, SeqTypes::Auto);
+        auto tf_cap = make_shared<TensorFunctions<S, FL>>(opf_cap);
+        shared_ptr<Symbolic<S>> exprs = cexprs != nullptr ? cexprs : (right ? b->rmat * a->rmat : a->lmat * b->lmat);
+        const auto &names = right ? c->rmat->data : c->lmat->data;
+        assert(exprs->data.size() == names.size());
+        set<const void *> seen;
+        struct CBlock {
+            const double *p;
+            int rows, cols;
+        };
+        vector<CBlock> cblocks;
+        vector<pair<const double *, size_t>> xr, sr, vr;
+        for (size_t i = 0; i < names.size(); i++) {
+            auto cop = dynamic_pointer_cast<OpElement<S, FL>>(names[i]);
+            auto op = abs_value(names[i]);
+            auto cm = c->ops.at(op);
+            if (!seen.insert(cm.get()).second)
+                continue;
+            auto expr = exprs->data[i] * (1.0 / cop->factor);
+            if (right)
+                tf_cap->tensor_product(expr, b->ops, a->ops, cm);
+            else
+                tf_cap->tensor_product(expr, a->ops, b->ops, cm);
+            vr.push_back(make_pair((const double *)cm->data, (size_t)cm->total_memory));
+            for (int k = 0; k < cm->info->n; k++)
+                cblocks.push_back(CBlock{cm->data + cm->info->n_states_total[k], (int)cm->info->n_states_bra[k],
+                                         (int)cm->info->n_states_ket[k]});
+        }
+        for (auto &kv : a->ops)
+            if (kv.second->data != nullptr)
+                xr.push_back(make_pair((const double *)kv.second->data, (size_t)kv.second->total_memory));
+        for (auto &kv : b->ops)
+            if (kv.second->data != nullptr)
+                sr.push_back(make_pair((const double *)kv.second->data, (size_t)kv.second->total_memory));
+        sort(cblocks.begin(), cblocks.end(), [](const CBlock &x, const CBlock &y) { return x.p < y.p; });
+        Packed2 X, Sx, V;
+        X.build(xr), Sx.build(sr), V.build(vr);
+        auto b0 = opf_cap->seq->batch[0], b1 = opf_cap->seq->batch[1];
+        stringstream fn;
+        fn << spec->prefix << ".sw" << key.first << ".c" << key.second << (right ? ".rblk" : ".lblk");
+        if (b0->c.size() != 0) {
+            cerr << "BLK " << fn.str() << " skipped: two-stage records present" << endl;
+            return;
+        }
+        if (b1->acc_gp.size() != b1->gp.size())
+            b1->build_acc_gp();
+        vector<b2x_outer_term> terms;
+        bool ok = true;
+        uint64_t n_members = 0;
+        for (size_t g = 0; g < b1->gp.size() && ok; g++) {
+            const size_t kz = b1->acc_gp[g], gc = b1->gp[g];
+            ok = b1->n[g] == 1 && b1->k[g] == 1 && b1->beta[g] == 1.0 && b1->ta[g] == CblasNoTrans;
+            n_members += gc;
+            size_t k = kz;
+            while (k < kz + gc && ok) {
+                // maximal run with constant steps and one scalar
+                size_t e = k + 1;
+                ptrdiff_t da = 0, dc = 0;
+                if (e < kz + gc && b1->b[e] == b1->b[k]) {
+                    da = b1->a[e] - b1->a[k], dc = b1->c[e] - b1->c[k];
+                    if (da >= 0 && dc >= (ptrdiff_t)b1->m[g]) {
+                        e++;
+                        while (e < kz + gc && b1->b[e] == b1->b[k] && b1->a[e] - b1->a[e - 1] == da &&
+                               b1->c[e] - b1->c[e - 1] == dc)
+                            e++;
+                    } else
+                        da = dc = 0;
+                }
+                b2x_outer_term t;
+                memset(&t, 0, sizeof(t));
+                t.m = (int)(e - k), t.n = b1->m[g], t.a_rs = (int)da, t.a_cs = b1->lda[g];
+                t.ldc = t.m > 1 ? (int)dc : t.n;
+                t.alpha = b1->alpha[g];
+                // operands: the vector comes from the block operators (input) or from the site operators (arena)
+                uint64_t off;
+                if (X.resolve(b1->a[k], off))
+                    t.a_src = 1, t.a_off = off;
+                else if (Sx.resolve(b1->a[k], off))
+                    t.a_src = 0, t.a_off = off + (1ull << 40); // site arena follows; fixed up below
+                else
+                    ok = false;
+                if (ok && X.resolve(b1->b[k], off))
+                    t.b_src = 1, t.b_off = off;
+                else if (ok && Sx.resolve(b1->b[k], off))
+                    t.b_src = 0, t.b_off = off + (1ull << 40);
+                else
+                    ok = false;
+                if (ok && !V.resolve(b1->c[k], off))
+                    ok = false;
+                t.c_off = off;
+                if (ok && t.m == 1) {
+                    // a single contiguous member may span several rows of its block: give it the block's shape
+                    auto it = upper_bound(cblocks.begin(), cblocks.end(), b1->c[k],
+                                          [](const double *p, const CBlock &x) { return p < x.p; });
+                    assert(it != cblocks.begin());
+                    --it;
+                    const int cols = it->cols;
+                    const ptrdiff_t rel = b1->c[k] - it->p;
+                    if (cols > 0 && rel % cols == 0 && t.n > cols && t.n % cols == 0) {
+                        t.m = t.n / cols, t.n = cols, t.ldc = cols, t.a_rs = cols * t.a_cs;
+                    }
+                }
+                terms.push_back(t);
+                k = e;
+            }
+        }
+        if (!ok) {
+            cerr << "BLK " << fn.str() << " skipped: record outside the operator ranges (temporaries)" << endl;
+            opf_cap->seq->clear();
+            return;
+        }
+        for (auto &t : terms) {
+            if (t.a_src == 0)
+                t.a_off -= (1ull << 40);
+            if (t.b_src == 0)
+                t.b_off -= (1ull << 40);
+        }
+        {
+            ArrayFile af(fn.str() + ".blk");
+            af.put("terms", 4, 1, terms.data(), terms.size() * sizeof(b2x_outer_term));
+            af.u64("lens", vector<uint64_t>{(uint64_t)terms.size(), Sx.tot, X.tot, V.tot, (uint64_t)right, n_members,
+                                            (uint64_t)b1->gp.size(), (uint64_t)seen.size()});
+            if (with_data)
+                af.f64("arena", Sx.gather()), af.f64("in", X.gather()), af.f64("out_ref", V.gather());
+        }
+        stringstream ss;
+        ss << "BLK " << fn.str() << ".blk terms=" << terms.size() << " groups=" << b1->gp.size() << " members=" << n_members
+           << " ops=" << seen.size() << " in=" << X.tot << " site=" << Sx.tot << " out=" << V.tot;
+        if (log)
+            log->push_back(ss.str());
+        cerr << ss.str() << endl;
+        opf_cap->seq->clear();
     }
     void maybe_capture(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<SparseMatrix<S, FL>> &bra,
                        const shared_ptr<SparseMatrix<S, FL>> &ket, const shared_ptr<OperatorTensor<S, FL>> &c,
@@ -752,7 +948,12 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
         dumper->spec.rot_struct = parse_pairs(kv["rot_struct"]);
     if (kv.count("erot"))
         dumper->spec.erot = parse_pairs(kv["erot"]);
-    if (!dumper->spec.rot.empty() || !dumper->spec.rot_struct.empty() || !dumper->spec.erot.empty()) {
+    if (kv.count("blk"))
+        dumper->spec.blk = parse_pairs(kv["blk"]);
+    if (kv.count("blk_struct"))
+        dumper->spec.blk_struct = parse_pairs(kv["blk_struct"]);
+    if (!dumper->spec.rot.empty() || !dumper->spec.rot_struct.empty() || !dumper->spec.erot.empty() ||
+        !dumper->spec.blk.empty() || !dumper->spec.blk_struct.empty()) {
         auto rtf = make_shared<RotTF<S>>(mpo->tf->opf);
         rtf->dmrg = dmrg.get(), rtf->spec = &dumper->spec, rtf->log = &dumper->log;
         mpo->tf = rtf; // MovingEnvironment rotates through mpo->tf (src/dmrg/moving_environment.hpp:360)
