@@ -519,30 +519,57 @@ hipError_t launch_diag(const DiagComp *comps, uint32_t n_comps, const DiagTermD 
 }
 
 // out[cell] += sum over the cell's entries of alpha * A[r][c] * B[r][c]: element-wise block products of the blocking step
-// (a (x) scalar site operator, operator sums).  One workgroup per work unit (an element range of one cell); a thread
-// owns elements and walks the entry list in plan order with no window test: deterministic, no atomics.  HBM-bound:
-// every operand element is read once, consecutive lanes read consecutive addresses when the block is not transposed.
-__global__ __launch_bounds__(256) void outer_build_k(const OWork *__restrict__ work, const OEntry *__restrict__ entries,
-                                                      const double *__restrict__ arena, const double *__restrict__ in,
-                                                      double *__restrict__ out) {
-    const OWork W = work[blockIdx.x];
-    for (uint32_t e = W.e_begin + threadIdx.x; e < W.e_end; e += 256) {
-        const uint32_t r = e / (uint32_t)W.cols, c = e - r * (uint32_t)W.cols;
-        double sum = 0.0;
-        for (uint32_t k = W.entry_begin; k < W.entry_end; k++) {
-            const OEntry T = entries[k];
-            const double a = T.a_src == 2 ? 1.0 : (T.a_src ? in : arena)[T.a_off + (uint64_t)r * T.a_rs + (uint64_t)c * T.a_cs];
-            const double b = T.b_src == 2 ? 1.0 : (T.b_src ? in : arena)[T.b_off + (uint64_t)r * T.b_rs + (uint64_t)c * T.b_cs];
-            sum += T.alpha * a * b;
+// (a (x) scalar site operator, operator sums).  ONE WAVE per work unit (a few 64-column x rpt-row tiles of one cell; the
+// many small symmetry blocks give tens of thousands of units, so four independent waves share a workgroup only for
+// dispatch).  Lane = column, the wave walks the tile's rows four at a time (4 x entries loads in flight) and the
+// entry list in plan order with no window test: deterministic, no atomics.  HBM-bound: non-transposed blocks are read
+// as 512-byte row segments; a transposed block is read with one cache line per lane that the next rows reuse from L1/L2.
+__global__ __launch_bounds__(256) void outer_build_k(const OWork *__restrict__ work, uint32_t n_work,
+                                                      const OEntry *__restrict__ entries, const double *__restrict__ arena,
+                                                      const double *__restrict__ in, double *__restrict__ out) {
+    const uint32_t unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (unit >= n_work)
+        return;
+    const int lane = threadIdx.x & 63;
+    const OWork W = work[unit];
+    const uint32_t nseg = (uint32_t)(W.cols + 63) >> 6;
+    for (uint32_t tile = W.t_begin; tile < W.t_end; tile++) {
+        const int r0 = (int)(tile / nseg) * W.rpt, c = (int)(tile % nseg) * 64 + lane;
+        const int r1 = min(W.rows, r0 + W.rpt);
+        const bool live = c < W.cols;
+        const uint64_t cc = (uint64_t)min(c, W.cols - 1); // clamped: dead lanes load a valid element and drop it
+        for (int r = r0; r < r1; r += 4) {
+            double sum[4] = {0.0, 0.0, 0.0, 0.0};
+            uint64_t rr[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                rr[u] = (uint64_t)min(r + u, r1 - 1);
+            for (uint32_t k = W.entry_begin; k < W.entry_end; k++) {
+                const OEntry T = entries[k];
+                const double *pa = (T.a_src == 1 ? in : arena) + T.a_off + cc * (uint64_t)T.a_cs;
+                const double *pb = (T.b_src == 1 ? in : arena) + T.b_off + cc * (uint64_t)T.b_cs;
+                double a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    a[u] = pa[rr[u] * (uint64_t)T.a_rs], b[u] = pb[rr[u] * (uint64_t)T.b_rs];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    sum[u] += T.alpha * (T.a_src == 2 ? 1.0 : a[u]) * (T.b_src == 2 ? 1.0 : b[u]);
+            }
+            if (live) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (r + u < r1)
+                        out[W.out_off + (uint64_t)(r + u) * W.ld + c] += sum[u];
+            }
         }
-        out[W.out_off + (uint64_t)r * W.ld + c] += sum;
     }
 }
 hipError_t launch_outer(const OWork *work, uint32_t n_work, const OEntry *entries, const double *arena, const double *in,
                         double *out, hipStream_t st) {
     if (n_work == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(outer_build_k, dim3(n_work), dim3(256), 0, st, work, entries, arena, in, out);
+    hipLaunchKernelGGL(outer_build_k, dim3((n_work + 3) / 4), dim3(256), 0, st, work, n_work, entries, arena, in, out);
     return hipGetLastError();
 }
 

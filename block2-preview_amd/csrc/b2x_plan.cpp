@@ -788,21 +788,29 @@ int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, si
                     e.b_off = t.b_off + (uint64_t)(dr * t.b_rs + dc * t.b_cs);
                     e.alpha = t.alpha, e.a_rs = t.a_rs, e.a_cs = t.a_cs, e.b_rs = t.b_rs, e.b_cs = t.b_cs;
                     e.a_src = t.a_src, e.b_src = t.b_src;
+                    if (t.a_src == 2) // the constant 1.0: the kernel still forms an address, keep it inside the arena
+                        e.a_off = 0, e.a_rs = e.a_cs = 0;
+                    if (t.b_src == 2)
+                        e.b_off = 0, e.b_rs = e.b_cs = 0;
                     entries.push_back(e);
                 }
                 OWork w{};
                 w.out_off = c.base + (uint64_t)rb[a] * c.ld + cb[b];
                 w.ld = c.ld, w.rows = rb[a + 1] - rb[a], w.cols = cb[b + 1] - cb[b];
                 w.entry_begin = eb, w.entry_end = (uint32_t)entries.size();
-                const uint64_t ne = (uint64_t)w.rows * w.cols;
-                if (ne > 0xFFFFFFFFull) {
-                    err = "outer cell larger than 2^32 elements";
+                // tiles: 64 columns x rpt rows, rpt sized so that a tile carries a few thousand element-term products;
+                // a unit (one wave) takes up to 4 consecutive tiles
+                const int T = (int)lst.size();
+                w.rpt = std::max(4, std::min(64, 256 / std::max(1, T)));
+                const uint32_t nseg = (uint32_t)ceil_div(w.cols, kOuterTileCols), nstrip = (uint32_t)ceil_div(w.rows, w.rpt);
+                const uint64_t ntile = (uint64_t)nseg * nstrip;
+                if (ntile > 0xFFFFFFFFull) {
+                    err = "outer cell with more than 2^32 tiles";
                     return B2X_ERR_INVALID;
                 }
-                // chunk so that a unit carries ~kOuterChunk element-term products
-                uint64_t per = std::max<uint64_t>(256, (uint64_t)kOuterChunk * 4 / std::max<size_t>(1, std::min<size_t>(lst.size(), 64)));
-                for (uint64_t e0 = 0; e0 < ne; e0 += per) {
-                    w.e_begin = (uint32_t)e0, w.e_end = (uint32_t)std::min(ne, e0 + per);
+                const uint32_t per = ntile >= 4096 ? 4 : (ntile >= 1024 ? 2 : 1);
+                for (uint64_t t0 = 0; t0 < ntile; t0 += per) {
+                    w.t_begin = (uint32_t)t0, w.t_end = (uint32_t)std::min<uint64_t>(ntile, t0 + per);
                     work.push_back(w);
                 }
             }
@@ -813,18 +821,23 @@ int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, si
 void emulate_outer_host(const std::vector<OWork> &work, const std::vector<OEntry> &entries, const double *arena,
                         const double *in, double *out) {
     static const double one = 1.0;
-    for (const OWork &w : work)
-        for (uint32_t e = w.e_begin; e < w.e_end; e++) {
-            const int r = (int)(e / (uint32_t)w.cols), c = (int)(e % (uint32_t)w.cols);
-            double sum = 0.0;
-            for (uint32_t k = w.entry_begin; k < w.entry_end; k++) {
-                const OEntry &t = entries[k];
-                const double a = t.a_src == 2 ? one : (t.a_src ? in : arena)[t.a_off + (uint64_t)r * t.a_rs + (uint64_t)c * t.a_cs];
-                const double b = t.b_src == 2 ? one : (t.b_src ? in : arena)[t.b_off + (uint64_t)r * t.b_rs + (uint64_t)c * t.b_cs];
-                sum += t.alpha * a * b;
-            }
-            out[w.out_off + (uint64_t)r * w.ld + c] += sum;
+    for (const OWork &w : work) {
+        const uint32_t nseg = (uint32_t)ceil_div(w.cols, kOuterTileCols);
+        for (uint32_t tile = w.t_begin; tile < w.t_end; tile++) {
+            const int r0 = (int)(tile / nseg) * w.rpt, c0 = (int)(tile % nseg) * kOuterTileCols;
+            for (int r = r0; r < std::min(w.rows, r0 + w.rpt); r++)
+                for (int c = c0; c < std::min(w.cols, c0 + kOuterTileCols); c++) {
+                    double sum = 0.0;
+                    for (uint32_t k = w.entry_begin; k < w.entry_end; k++) {
+                        const OEntry &t = entries[k];
+                        const double a = t.a_src == 2 ? one : (t.a_src ? in : arena)[t.a_off + (uint64_t)r * t.a_rs + (uint64_t)c * t.a_cs];
+                        const double b = t.b_src == 2 ? one : (t.b_src ? in : arena)[t.b_off + (uint64_t)r * t.b_rs + (uint64_t)c * t.b_cs];
+                        sum += t.alpha * a * b;
+                    }
+                    out[w.out_off + (uint64_t)r * w.ld + c] += sum;
+                }
         }
+    }
 }
 
 int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,

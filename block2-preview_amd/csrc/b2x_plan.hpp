@@ -130,7 +130,8 @@ struct DiagComp {
 // ---- element-wise block products (blocking) ---------------------------------------------------------------------
 // The windows of one output sector are cut along all their row / column boundaries into CELLS; a cell lists the terms
 // that cover it with operand offsets already moved to the cell origin, so the kernel walks a cell's list without any
-// window test.  Work units are element ranges of a cell (<= kOuterChunk elements).
+// window test.  A cell is covered by TILES of 64 columns x rpt rows (tile id = strip * n_col_segments + segment); a
+// work unit is a range of tiles of one cell and is executed by ONE WAVE (four units per workgroup).
 struct OEntry {
     uint64_t a_off, b_off;
     double alpha;
@@ -141,12 +142,12 @@ static_assert(sizeof(OEntry) == 48, "OEntry layout");
 struct OWork {
     uint64_t out_off; // output offset of the cell's (0, 0)
     int32_t ld, rows, cols;
-    uint32_t e_begin, e_end;       // element range of the cell handled by this unit
+    int32_t rpt;                   // rows per tile
+    uint32_t t_begin, t_end;       // tile range of the cell handled by this unit
     uint32_t entry_begin, entry_end;
-    uint32_t pad;
 };
 static_assert(sizeof(OWork) == 40, "OWork layout");
-static const uint32_t kOuterChunk = 16384;
+static const int kOuterTileCols = 64;
 int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, size_t out_len, uint64_t arena_len,
                   std::vector<OWork> &work, std::vector<OEntry> &entries, std::string &err);
 // host evaluation of the compiled work list (TEST HOOK)

@@ -196,3 +196,18 @@ def write_gemm_struct_npz(fn, gl):
     cols = {n: gl.gemms[n] for n in GEMM_DTYPE.names if n != "reserved"}
     lens = np.array([len(gl.gemms), gl.arena_len, gl.in_len, gl.out_len, len(gl.out_lens), gl.macs, gl.forward], "<u8")
     np.savez_compressed(fn, lens=lens, out_offsets=gl.out_offsets, out_lens=gl.out_lens, **cols)
+
+
+def write_outer_struct_npz(fn, terms, lens):
+    """blocking term list without data (structure of a Cr2-size blocking step) as compressed columns"""
+    cols = {n: terms[n] for n in OUTER_TERM_DTYPE.names if n != "reserved"}
+    np.savez_compressed(fn, lens=np.asarray(lens, "<u8"), **cols)
+
+
+def read_outer_struct_npz(fn):
+    z = np.load(fn, allow_pickle=False)
+    t = np.zeros(len(z["m"]), OUTER_TERM_DTYPE)
+    for name in OUTER_TERM_DTYPE.names:
+        if name != "reserved":
+            t[name] = z[name]
+    return t, z["lens"].copy()

@@ -88,3 +88,24 @@ def test_kron_and_iadd_semantics(gpu):
     seq.iadd((z, 0, 6, 4), x, 2.0, True)
     seq.outer_perform(z)
     assert _close(z, z0 + (2.0 * x.T).ravel())
+
+
+def test_cr2_blocking_structure(gpu):
+    """Cr2/SVP M=250 blocking (31k terms, structure recorded by the reference), synthetic data: vs oracle"""
+    import glob
+
+    from conftest import GOLDEN
+    from block2_preview_amd.planfile import read_outer_struct_npz
+
+    fn = sorted(glob.glob(os.path.join(GOLDEN, "*sw1_c20_rblk.blkstruct.npz")))[0]
+    t, lens = read_outer_struct_npz(fn)
+    in_len, out_len = int(lens[2]), int(lens[3])
+    rng = np.random.default_rng(8)
+    arena, vin = rng.random(int(lens[1])) - 0.5, rng.random(in_len) - 0.5
+    ref = np.zeros(out_len)
+    oracle.outer(t, arena, vin, ref)
+    ar = gpu.Arena.from_host([arena])
+    out = np.zeros(out_len)
+    gpu.outer_build(ar, t, vin, out)
+    ar.close()
+    assert _close(out, ref)
