@@ -321,7 +321,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     // them.  Left alone, hipcc hoists all 4*TMF ds_reads to the top of the block (2 VGPRs each), which at
     // TMF = 16 exceeds the 256-VGPR budget of two waves per SIMD and spills inside the loop.
     auto pin_schedule = [&]() __attribute__((always_inline)) {
-        constexpr int LEAD = 6, NRD = KS * TMF;
+        constexpr int NRD = KS * TMF, LEAD = NRD < 6 ? NRD : 6;
         __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0); // DS reads
 #pragma unroll
         for (int i = 0; i < NRD - LEAD; i++) {
@@ -409,8 +409,9 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     }
 }
 
-// One launch per stage: every workgroup picks the body specialised for its item's tile height (64-row units), so
-// tiles of all heights share a grid (no per-variant launch tails) and one LDS allocation.
+// One launch per stage: every workgroup picks the body specialised for its item's tile height (one body per number
+// of 16-row fragments, 1..16), so tiles of all heights share a grid (no per-variant launch tails) and one LDS
+// allocation, and no MFMA is issued on padding rows beyond the last fragment.
 template <int CF, int NW, int KC, bool SB>
 __global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
                                                          const double *__restrict__ arena,
@@ -418,15 +419,18 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__
                                                          double *__restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) double lds[2 * 256 * KC];
     const GItem item = items[blockIdx.x];
-    const int v = (item.rows - 1) >> 6;
-    if (v == 0)
-        gg_body<4, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
-    else if (v == 1)
-        gg_body<8, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
-    else if (v == 2)
-        gg_body<12, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
-    else
+#define B2X_GG_CASE(T)                                                                                                 \
+    case T:                                                                                                            \
+        gg_body<T, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);                                       \
+        break;
+    switch ((item.rows + 15) >> 4) { // row fragments of the tile
+        B2X_GG_CASE(1) B2X_GG_CASE(2) B2X_GG_CASE(3) B2X_GG_CASE(4) B2X_GG_CASE(5) B2X_GG_CASE(6) B2X_GG_CASE(7)
+        B2X_GG_CASE(8) B2X_GG_CASE(9) B2X_GG_CASE(10) B2X_GG_CASE(11) B2X_GG_CASE(12) B2X_GG_CASE(13) B2X_GG_CASE(14)
+        B2X_GG_CASE(15)
+    default:
         gg_body<16, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
+    }
+#undef B2X_GG_CASE
 }
 
 // psi'[tile] += scale * sum_i slab_i[tile]   (fixed order i = 0..n_items-1)

@@ -37,16 +37,16 @@ std::vector<int> balanced_cuts(int total, int max_piece) {
     return cuts;
 }
 
-// Row cuts for the grouped-GEMM kernel, whose tile-height variants are multiples of 64 rows (<= 256):
-// split `total` into ceil(U/4) pieces of near-equal size in units of 64 (U = ceil(total/64)), so the issued
-// rows are 64*U (the minimum) and no piece is needlessly small.
+// Row cuts for the grouped-GEMM kernel, which has a body for every tile height that is a multiple of 16 rows
+// (<= 256): split `total` into ceil(U/16) pieces of near-equal size in units of 16 (U = ceil(total/16)), so the
+// issued rows are 16*U (the minimum) and no piece is needlessly small.
 std::vector<int> unit_cuts(int total) {
-    const int U = ceil_div(total, 64), n = ceil_div(U, 4);
+    const int U = ceil_div(total, kGGRowUnit), n = ceil_div(U, kGGTileM / kGGRowUnit);
     std::vector<int> cuts{0};
     int pos = 0;
     for (int i = 0; i < n; i++) {
         int units = U / n + (i < U % n ? 1 : 0);
-        pos = std::min(total, pos + units * 64);
+        pos = std::min(total, pos + units * kGGRowUnit);
         cuts.push_back(pos);
     }
     cuts.back() = total;
@@ -459,7 +459,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             const uint32_t s1_end = (uint32_t)out.gitems.size();
             ss.tile_end = (uint32_t)out.gtiles.size();
             // group by tile-height variant; inside a variant, longest items first
-            auto variant = [](const GItem &x) { return std::min(kGGVariants - 1, (x.rows - 1) / 64); };
+            auto variant = [](const GItem &x) { return (x.rows - 1) / kGGRowUnit; }; // row fragments - 1
             // one grid per stage holds the items of all tile heights: longest (by MFMA issue slots) first
             auto icost = [&](const GItem &x) {
                 uint64_t k = 0;
@@ -479,7 +479,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             fill(s1_begin, s1_end, ss.s1_v);
             for (uint32_t ii = s0_begin; ii < s1_end; ii++) {
                 const GItem &it = out.gitems[ii];
-                uint64_t tm = 64 * (uint64_t)(variant(it) + 1);
+                uint64_t tm = (uint64_t)kGGRowUnit * (uint64_t)(variant(it) + 1);
                 for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
                     st.macs_issued += tm * TN * (uint64_t)round_up(out.gsegs[k].K, 16);
             }
@@ -675,7 +675,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
                 out.gtiles.push_back(dt);
             }
     }
-    auto variant = [](const GItem &x) { return std::min(kGGVariants - 1, (x.rows - 1) / 64); };
+    auto variant = [](const GItem &x) { return (x.rows - 1) / kGGRowUnit; }; // row fragments - 1
     auto icost = [&](const GItem &x) {
         uint64_t k = 0;
         for (uint32_t q = x.seg_begin; q < x.seg_end; q++)
@@ -688,7 +688,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     ss.s1_v[kGGVariants] = (uint32_t)out.gitems.size();
     ss.tile_begin = 0, ss.tile_end = (uint32_t)out.gtiles.size();
     for (const GItem &it : out.gitems) {
-        uint64_t tm = 64 * (uint64_t)(variant(it) + 1);
+        uint64_t tm = (uint64_t)kGGRowUnit * (uint64_t)(variant(it) + 1);
         for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
             st.macs_issued += tm * TN * (uint64_t)round_up(out.gsegs[k].K, 16);
     }

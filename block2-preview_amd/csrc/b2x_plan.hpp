@@ -71,8 +71,8 @@ struct GItem {
 static_assert(sizeof(GItem) == 40, "GItem layout");
 
 // stage 0 of a batch of pairs -> W scratch; stage 1 consumes it; reduce adds the slabs into psi'.
-// Items are grouped by tile-height variant v (tile rows <= 64*(v+1)): variant v of stage s is the GItem
-// range [s?_v[v], s?_v[v+1]) and is launched with gg_kernel<4*(v+1), ...>.
+// All items of a stage share one launch (range [s?_v[0], s?_v[kGGVariants])); every workgroup picks the kernel body
+// for its tile height (rows rounded up to 16).
 static const int kGGVariants = 4;
 struct SuperStep {
     uint32_t s0_v[kGGVariants + 1];
@@ -81,6 +81,7 @@ struct SuperStep {
 };
 
 static const int kGGTileM = 256, kGGTileN = 128;
+static const int kGGRowUnit = 16; // tile heights are multiples of one MFMA row fragment
 
 // kernel classes of the fused path.  nw = tile width / 16, tmf = tile height / 16, k1f = k1 chunk / 16.
 // All fused classes run hpsi_wave — one WAVE per work item, operands straight from L2 into MFMA fragments, no LDS,
