@@ -12,6 +12,7 @@
 #include "b2x_kernels.h"
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 
 namespace b2x {
 
@@ -320,8 +321,8 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     // Pin the issue order inside the MFMA block: LDS reads run LEAD fragments ahead of the MFMAs that consume
     // them.  Left alone, hipcc hoists all 4*TMF ds_reads to the top of the block (2 VGPRs each), which at
     // TMF = 16 exceeds the 256-VGPR budget of two waves per SIMD and spills inside the loop.
-    auto pin_schedule = [&]() __attribute__((always_inline)) {
-        constexpr int NRD = KS * TMF, LEAD = NRD < 6 ? NRD : 6;
+    auto pin_schedule = [&](auto nks) __attribute__((always_inline)) {
+        constexpr int NRD = decltype(nks)::value * TMF, LEAD = NRD < 6 ? NRD : 6;
         __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0); // DS reads
 #pragma unroll
         for (int i = 0; i < NRD - LEAD; i++) {
@@ -337,25 +338,27 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     //   rowmaj image: (row, k) at row*KC + 2*((k>>1) ^ swz(row)) + (k&1),  swz = (row>>1)&7 (KC 16) or row&15 (KC 32)
     //   kmaj   image: (row, k) at (row>>4)*16*KC + k*16 + (row&15)         (conflict-free as it stands)
     // with row = f*16 + c, k = 4s + g.
-    auto compute = [&](const double *As, bool kmaj) __attribute__((always_inline)) {
+    // k-steps [S0, S0 + NS) of the chunk
+    auto compute = [&](const double *As, bool kmaj, auto s0c, auto nsc) __attribute__((always_inline)) {
+        constexpr int S0 = decltype(s0c)::value, NS = decltype(nsc)::value;
         const int sw = KC == 16 ? ((c >> 1) & 7) : c;
-        const double *pb[KS];
+        const double *pb[NS];
 #pragma unroll
-        for (int s = 0; s < KS; s++) {
-            const int o_row = c * KC + 2 * ((2 * s + (g >> 1)) ^ sw) + (g & 1);
-            const int o_k = (4 * s + g) * 16 + c;
+        for (int s = 0; s < NS; s++) {
+            const int o_row = c * KC + 2 * ((2 * (S0 + s) + (g >> 1)) ^ sw) + (g & 1);
+            const int o_k = (4 * (S0 + s) + g) * 16 + c;
             pb[s] = As + (kmaj ? o_k : o_row);
         }
 #pragma unroll
-        for (int s = 0; s < KS; s++)
+        for (int s = 0; s < NS; s++)
 #pragma unroll
             for (int f = 0; f < TMF; f++) {
                 double a = pb[s][f * 16 * KC];
 #pragma unroll
                 for (int q = 0; q < CF; q++)
-                    acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][s], acc[f][q], 0, 0, 0);
+                    acc[f][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bcur[q][S0 + s], acc[f][q], 0, 0, 0);
             }
-        pin_schedule();
+        pin_schedule(nsc);
     };
 
     uint32_t si = item.seg_begin;
@@ -367,20 +370,43 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         commit();
         bool cur_kmaj = s_kmaj;
         __syncthreads(); // drains the DMA (vmcnt(0)) and publishes the image
+        // Stagger the SIMD partners (waves w and w + NW/2 run on the same SIMD with the same program and one barrier
+        // per chunk): the first half of the waves issues the next chunk's loads BEFORE the MFMA block, the second half
+        // in the MIDDLE of it, so one partner's address arithmetic / load issue overlaps the other's MFMAs instead of
+        // leaving the matrix pipe idle in both (MI355X_MICROARCH.md, wave-stagger note).
+        const bool early = wave < NW / 2;
+        constexpr int KH = KS / 2;
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, KH>;
+        using NH0 = std::integral_constant<int, KH>;
+        using NH1 = std::integral_constant<int, KS - KH>;
         while (true) {
             uint32_t nsi = si;
             int nkb = kb + KC;
             if (nkb >= S.K)
                 nsi = si + 1, nkb = 0;
             const bool more = nsi < item.seg_end;
-            if (more && nsi != si) {
-                S = segs[nsi];
-                enter(S);
+            if (early) {
+                if (more && nsi != si) {
+                    S = segs[nsi];
+                    enter(S);
+                }
+                if (more)
+                    fetch(S, nkb, lds + (buf ^ 1) * ABUF);
             }
-            if (more)
-                fetch(S, nkb, lds + (buf ^ 1) * ABUF);
             __builtin_amdgcn_sched_barrier(0); // loads issued; nothing below may move above them
-            compute(lds + buf * ABUF, cur_kmaj);
+            compute(lds + buf * ABUF, cur_kmaj, H0{}, NH0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (!early) {
+                if (more && nsi != si) {
+                    S = segs[nsi];
+                    enter(S);
+                }
+                if (more)
+                    fetch(S, nkb, lds + (buf ^ 1) * ABUF);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            compute(lds + buf * ABUF, cur_kmaj, H1{}, NH1{});
             __builtin_amdgcn_sched_barrier(0);
             if (!more)
                 break;
