@@ -352,6 +352,29 @@ template <typename S> struct OperatorFunctions {
     std::shared_ptr<BatchGEMMSeq> seq;
     CG<S> cg;
     explicit OperatorFunctions(const std::shared_ptr<BatchGEMMSeq> &seq) : seq(seq) {}
+    // c += scale * factor * op(a[ia]) (x) op(b[ib]) for every connection of the matching sub-label (blocking; reference
+    // operator_functions.hpp:672-711).  The connection info of c (ConnectionInfo::initialize_tp, built by the reference's
+    // Partition layer) lists (ia, ib, ic, stride, factor): block ic of the enlarged operator receives the Kronecker
+    // product in the window that starts `stride` elements after its first element.
+    void tensor_product(uint8_t conj, const SparseMatrix<S> &a, const SparseMatrix<S> &b, const SparseMatrix<S> &c,
+                        double scale = 1.0) const {
+        scale = scale * a.factor * b.factor;
+        if (std::fabs(scale) < 1E-20)
+            return;
+        S adq = a.info->delta_quantum, bdq = b.info->delta_quantum, cdq = c.info->delta_quantum;
+        if (!c.info->cinfo)
+            throw std::runtime_error("tensor_product: missing connection info");
+        const auto &ci = *c.info->cinfo;
+        S abdq = cdq.combine((conj & 1) ? -adq : adq, (conj & 2) ? bdq : -bdq);
+        int ik = (int)(std::lower_bound(ci.quanta.begin() + ci.n[conj], ci.quanta.begin() + ci.n[conj + 1], abdq) -
+                       ci.quanta.begin());
+        if (ik >= ci.n[conj + 1] || ci.quanta[ik] != abdq)
+            throw std::runtime_error("tensor_product: sub-label not in the connection info");
+        int ixa = (int)ci.idx[ik], ixb = ik == ci.n[4] - 1 ? ci.nc : (int)ci.idx[ik + 1];
+        for (int il = ixa; il < ixb; il++)
+            seq->tensor_product(a[(int)ci.ia[il]], conj & 1, b[(int)ci.ib[il]], (conj & 2) >> 1, c[(int)ci.ic[il]],
+                                scale * ci.factor[il], ci.stride[il]);
+    }
     // c[ic] += scale * op(rot_bra[cq]) a[ia] op(rot_ket[cq']) for every sector of c (operator_functions.hpp:175-210):
     // a is the operator in the enlarged basis (more sectors than c), the MPS tensor blocks are looked up by the bra /
     // ket labels of the c sector; trans = false: bra^T . a . ket (left blocks), true: bra . a . ket^T (right blocks)
@@ -489,6 +512,28 @@ template <typename S> struct OperatorFunctions {
 template <typename S> struct TensorFunctions {
     std::shared_ptr<OperatorFunctions<S>> opf;
     explicit TensorFunctions(const std::shared_ptr<OperatorFunctions<S>> &opf) : opf(opf) {}
+    // mat += eval(expr): a sum of products  factor * lop[a] (x) rop[b]  (tensor_functions.hpp:2185-2286; a SumProd term
+    // whose operator sum exists as an intermediate is the product with that intermediate)
+    void tensor_product(const std::vector<OpTerm> &expr, const OperatorTensor<S> &lop, const OperatorTensor<S> &rop,
+                        const SparseMatrix<S> &mat) const {
+        for (const OpTerm &t : expr) {
+            if (t.a < 0 || t.b < 0 || t.a >= (int)lop.ops.size() || t.b >= (int)rop.ops.size() || !lop.ops[t.a] ||
+                !rop.ops[t.b])
+                throw std::runtime_error("tensor_product: term refers to an unknown operator");
+            opf->tensor_product(t.conj, *lop.ops[t.a], *rop.ops[t.b], mat, t.factor);
+        }
+    }
+    // c[i] = eval(exprs[i]) over (a, b) = (block operators, site operators): left_contract (tensor_functions.hpp:
+    // 2842-2885); right_contract (:2941-2983) passes the site operators as the left factor.  Records the block products;
+    // BatchGEMMSeq::outer_perform executes them.
+    void contract(const OperatorTensor<S> &lop, const OperatorTensor<S> &rop, const OperatorTensor<S> &c,
+                  const std::vector<std::vector<OpTerm>> &exprs) const {
+        if (exprs.size() != c.ops.size())
+            throw std::runtime_error("contract: one expression per enlarged operator expected");
+        for (size_t i = 0; i < c.ops.size(); i++)
+            if (c.ops[i])
+                tensor_product(exprs[i], lop, rop, *c.ops[i]);
+    }
     // c = mpst_bra^T x a x mpst_ket for every operator of the enlarged block (tensor_functions.hpp:2365-2383);
     // right_rotate: c = mpst_bra x a x mpst_ket^T (:2385-2403).  Operators absent from a (null) are skipped.  The pairs
     // are recorded; BatchGEMMSeq::rotate_perform executes them.

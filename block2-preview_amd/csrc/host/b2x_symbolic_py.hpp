@@ -281,7 +281,92 @@ template <typename S> py::tuple sym_rotate(const py::dict &d, bool execute) {
     return py::make_tuple(pa, v);
 }
 
+// Blocking from a symbolic-level fixture (oracle/ref_dump.cpp `eblk=`): operator infos (the enlarged ones with their
+// tensor-product connection info), the flattened expression of every enlarged operator, data.  TensorFunctions::contract
+// records the block products through OperatorFunctions::tensor_product; execute = false returns them as b2x_outer_term
+// records (block operators = input vector, site operators = arena; no device needed), execute = true also runs them
+// (BatchGEMMSeq::outer_perform) and returns the enlarged operators.
+template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
+    typedef SparseMatrixInfo<S> Info;
+    std::map<int, std::shared_ptr<Info>> cache;
+    py::array_t<double> x = py::array_t<double>(py::array::ensure(d["x"]));
+    py::array_t<double> site = py::array_t<double>(py::array::ensure(d["site"]));
+    const uint64_t *meta = SymEH<S>::template arr<uint64_t>(d, "meta");
+    const bool right = meta[2] != 0;
+    if (!meta[3])
+        throw std::runtime_error("fixture holds expression forms this mirror does not cover (operator sums without an intermediate)");
+    py::array_t<double> v((py::ssize_t)meta[7]);
+    std::fill(v.mutable_data(), v.mutable_data() + v.size(), 0.0);
+    // lop / rop as TensorFunctions::tensor_product receives them: left blocking (block, site), right blocking (site, block)
+    auto load = [&](const std::string &pre, double *base) {
+        OperatorTensor<S> t;
+        size_t n;
+        const int64_t *iid = SymEH<S>::template arr<int64_t>(d, pre + ".info", &n), *off = SymEH<S>::template arr<int64_t>(d, pre + ".off");
+        const double *fac = SymEH<S>::template arr<double>(d, pre + ".factor");
+        for (size_t i = 0; i < n; i++) {
+            auto m = std::make_shared<SparseMatrix<S>>();
+            m->info = SymEH<S>::info(d, (int)iid[i], cache);
+            // (an operator without data has no blocks or is absent on this side: it contributes no connection)
+            m->factor = fac[i], m->data = off[i] < 0 ? nullptr : base + off[i];
+            m->total_memory = off[i] < 0 ? 0 : m->info->get_total_memory();
+            t.ops.push_back(m);
+        }
+        return t;
+    };
+    OperatorTensor<S> lop = load("lop", right ? site.mutable_data() : x.mutable_data());
+    OperatorTensor<S> rop = load("rop", right ? x.mutable_data() : site.mutable_data());
+    size_t nc;
+    const int64_t *ci = SymEH<S>::template arr<int64_t>(d, "c.info", &nc), *co = SymEH<S>::template arr<int64_t>(d, "c.off"),
+                  *tb = SymEH<S>::template arr<int64_t>(d, "c.term_begin");
+    const int64_t *ty = SymEH<S>::template arr<int64_t>(d, "term.type"), *cj = SymEH<S>::template arr<int64_t>(d, "term.conj"),
+                  *ta = SymEH<S>::template arr<int64_t>(d, "term.a"), *tbi = SymEH<S>::template arr<int64_t>(d, "term.b");
+    const double *tf = SymEH<S>::template arr<double>(d, "term.factor");
+    (void)ty;
+    OperatorTensor<S> c;
+    std::vector<std::vector<OpTerm>> exprs(nc);
+    for (size_t i = 0; i < nc; i++) {
+        auto m = std::make_shared<SparseMatrix<S>>();
+        m->info = SymEH<S>::info(d, (int)ci[i], cache);
+        m->factor = 1.0, m->data = v.mutable_data() + co[i], m->total_memory = m->info->get_total_memory();
+        c.ops.push_back(m);
+        for (int64_t k = tb[i]; k < tb[i + 1]; k++) {
+            OpTerm t;
+            t.factor = tf[k], t.conj = (uint8_t)cj[k], t.a = (int)ta[k], t.b = (int)tbi[k];
+            exprs[i].push_back(t);
+        }
+    }
+    auto seq = std::make_shared<BatchGEMMSeq>();
+    TensorFunctions<S> tfn(std::make_shared<OperatorFunctions<S>>(seq));
+    tfn.contract(lop, rop, c, exprs);
+    std::vector<b2x_outer_term> t = seq->outer_terms;
+    auto classify = [&](const double *p, uint8_t &src, uint64_t &off) {
+        if (p >= x.data() && p < x.data() + x.size())
+            src = 1, off = (uint64_t)(p - x.data());
+        else if (p >= site.data() && p < site.data() + site.size())
+            src = 0, off = (uint64_t)(p - site.data());
+        else
+            throw std::runtime_error("symbolic_blocking: operand outside the fixture's data");
+    };
+    for (size_t i = 0; i < t.size(); i++) {
+        classify(seq->oa_ptr[i], t[i].a_src, t[i].a_off);
+        classify(seq->ob_ptr[i], t[i].b_src, t[i].b_off);
+        t[i].c_off = (uint64_t)(seq->oc_ptr[i] - v.data());
+    }
+    py::array_t<uint8_t> pa(t.size() * sizeof(b2x_outer_term));
+    std::memcpy(pa.mutable_data(), t.data(), t.size() * sizeof(b2x_outer_term));
+    if (execute)
+        seq->outer_perform({{v.mutable_data(), (size_t)v.size()}});
+    return py::make_tuple(pa, v);
+}
+
 inline void bind_symbolic(py::module_ &m) {
+    m.def("symbolic_blocking", [](const std::string &sym, const py::dict &d, bool execute) {
+        if (sym == "sz")
+            return sym_blocking<SZ>(d, execute);
+        if (sym == "su2")
+            return sym_blocking<SU2>(d, execute);
+        throw std::runtime_error("symmetry must be 'sz' or 'su2'");
+    }, py::arg("sym"), py::arg("fixture"), py::arg("execute") = false);
     m.def("symbolic_rotate", [](const std::string &sym, const py::dict &d, bool execute) {
         if (sym == "sz")
             return sym_rotate<SZ>(d, execute);

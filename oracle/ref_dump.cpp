@@ -24,6 +24,8 @@
  *   blk=<sweep>:<center>[,...]               blocking (TensorFunctions::left_contract / right_contract called while
  *                                            center == <center>): element-wise block-product terms + data + result
  *   blk_struct=<sweep>:<center>[,...]        the same terms without data
+ *   eblk=<sweep>:<center>[,...]              blocking at the symbolic level (operator infos incl. the tensor-product
+ *                                            connection infos, the expression of every enlarged operator, data)
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
  */
 #include "block2_core.hpp"
@@ -36,7 +38,7 @@ using namespace block2;
 using namespace std;
 
 struct DumpSpec {
-    set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct, rot, rot_struct, erot, blk, blk_struct;
+    set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct, rot, rot_struct, erot, blk, blk_struct, eblk;
     string prefix;
 };
 
@@ -255,8 +257,8 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
         if (dmrg == nullptr || spec == nullptr || a == nullptr || !delayed.empty())
             return;
         pair<int, int> key(dmrg->isweep, dmrg->me->center);
-        const bool with_data = spec->blk.count(key);
-        if (!with_data && !spec->blk_struct.count(key))
+        const bool with_data = spec->blk.count(key), sym = spec->eblk.count(key);
+        if (!with_data && !spec->blk_struct.count(key) && !sym)
             return;
         {
             static set<string> done; // first call per (sweep, center, side) only
@@ -383,7 +385,81 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
             if (t.b_src == 0)
                 t.b_off -= (1ull << 40);
         }
-        {
+        if (sym) {
+            // what TensorFunctions::tensor_product(expr, lop, rop, mat) consumes: per enlarged operator the flattened
+            // expression (Prod terms; SumProd terms whose operator sum is an existing intermediate), the operator infos
+            // (the enlarged ones with their tensor-product connection info) and the data
+            EhamDump<S> ed(fn.str() + ".eblk");
+            ArrayFile &af = ed.af;
+            const auto &lt = right ? b : a, &rt = right ? a : b; // (lop, rop) as tensor_product receives them
+            vector<const double *> lp, rp;
+            auto lorder = ed.put_tensor("lop", lt, false, lp), rorder = ed.put_tensor("rop", rt, false, rp);
+            auto offs_in = [&](const vector<const double *> &ptrs, bool is_block) {
+                vector<int64_t> o;
+                for (auto p : ptrs) {
+                    uint64_t off = 0;
+                    if (p == nullptr || !(is_block ? X.resolve(p, off) : Sx.resolve(p, off)))
+                        o.push_back(-1);
+                    else
+                        o.push_back((int64_t)off);
+                }
+                return o;
+            };
+            af.i64("lop.off", offs_in(lp, !right)), af.i64("rop.off", offs_in(rp, right));
+            vector<int64_t> c_info, c_off, t_begin, ty, cj, ta, tb;
+            vector<double> tf;
+            bool supported = true;
+            set<const void *> seen2;
+            function<void(const shared_ptr<OpExpr<S>> &)> flat = [&](const shared_ptr<OpExpr<S>> &e) {
+                if (e->get_type() == OpTypes::Prod) {
+                    auto op = dynamic_pointer_cast<OpProduct<S, FL>>(e);
+                    if (op->b == nullptr) {
+                        supported = false;
+                        return;
+                    }
+                    ty.push_back(0), cj.push_back(op->conj), tf.push_back(op->factor);
+                    ta.push_back(EhamDump<S>::find_op(lt, lorder, op->a)), tb.push_back(EhamDump<S>::find_op(rt, rorder, op->b));
+                } else if (e->get_type() == OpTypes::SumProd) {
+                    auto op = dynamic_pointer_cast<OpSumProd<S, FL>>(e);
+                    const bool inter = op->c != nullptr && ((op->b == nullptr && rt->ops.count(op->c)) ||
+                                                            (op->a == nullptr && lt->ops.count(op->c)));
+                    if (!inter) {
+                        supported = false;
+                        return;
+                    }
+                    ty.push_back(1), cj.push_back(op->conj), tf.push_back(op->factor);
+                    if (op->b == nullptr)
+                        ta.push_back(EhamDump<S>::find_op(lt, lorder, op->a)), tb.push_back(EhamDump<S>::find_op(rt, rorder, op->c));
+                    else
+                        ta.push_back(EhamDump<S>::find_op(lt, lorder, op->c)), tb.push_back(EhamDump<S>::find_op(rt, rorder, op->b));
+                } else if (e->get_type() == OpTypes::Sum) {
+                    for (auto &x : dynamic_pointer_cast<OpSum<S, FL>>(e)->strings)
+                        flat(x);
+                } else if (e->get_type() != OpTypes::Zero)
+                    supported = false;
+            };
+            for (size_t i = 0; i < names.size(); i++) {
+                auto cop = dynamic_pointer_cast<OpElement<S, FL>>(names[i]);
+                auto cm = c->ops.at(abs_value(names[i]));
+                if (!seen2.insert(cm.get()).second)
+                    continue;
+                uint64_t off = 0;
+                if (cm->total_memory)
+                    V.resolve(cm->data, off);
+                c_info.push_back(ed.info_id(cm->info, true)), c_off.push_back((int64_t)off);
+                t_begin.push_back((int64_t)ty.size());
+                flat(exprs->data[i] * (1.0 / cop->factor));
+            }
+            t_begin.push_back((int64_t)ty.size());
+            af.i64("c.info", c_info), af.i64("c.off", c_off), af.i64("c.term_begin", t_begin);
+            af.i64("term.type", ty), af.i64("term.conj", cj), af.f64("term.factor", tf), af.i64("term.a", ta), af.i64("term.b", tb);
+            af.u64("meta", vector<uint64_t>{(uint64_t)key.first, (uint64_t)key.second, (uint64_t)right, (uint64_t)supported,
+                                            (uint64_t)terms.size(), X.tot, Sx.tot, V.tot});
+            af.f64("x", X.gather()), af.f64("site", Sx.gather()), af.f64("v_ref", V.gather());
+            cerr << "EBLK " << fn.str() << ".eblk ops=" << c_info.size() << " terms=" << ty.size()
+                 << " supported=" << supported << endl;
+        }
+        if (with_data || spec->blk_struct.count(key)) {
             ArrayFile af(fn.str() + ".blk");
             af.put("terms", 4, 1, terms.data(), terms.size() * sizeof(b2x_outer_term));
             af.u64("lens", vector<uint64_t>{(uint64_t)terms.size(), Sx.tot, X.tot, V.tot, (uint64_t)right, n_members,
@@ -952,8 +1028,10 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
         dumper->spec.blk = parse_pairs(kv["blk"]);
     if (kv.count("blk_struct"))
         dumper->spec.blk_struct = parse_pairs(kv["blk_struct"]);
+    if (kv.count("eblk"))
+        dumper->spec.eblk = parse_pairs(kv["eblk"]);
     if (!dumper->spec.rot.empty() || !dumper->spec.rot_struct.empty() || !dumper->spec.erot.empty() ||
-        !dumper->spec.blk.empty() || !dumper->spec.blk_struct.empty()) {
+        !dumper->spec.blk.empty() || !dumper->spec.blk_struct.empty() || !dumper->spec.eblk.empty()) {
         auto rtf = make_shared<RotTF<S>>(mpo->tf->opf);
         rtf->dmrg = dmrg.get(), rtf->spec = &dumper->spec, rtf->log = &dumper->log;
         mpo->tf = rtf; // MovingEnvironment rotates through mpo->tf (src/dmrg/moving_environment.hpp:360)

@@ -39,5 +39,8 @@ $R $D/CR2.SVP.FCIDUMP su2 250 2 ./rcr2 rot_struct=0:20,1:20 occ=$D/CR2.SVP.OCC n
 # blocking fixtures: the element-wise block-product terms re-grouped from the k = 1 GEMM groups the
 # reference's own TensorFunctions::tensor_product records (Auto mode) for left_contract / right_contract, the block and
 # site operators and the enlarged operators the reference computed
-$R $D/N2.STO3G.FCIDUMP su2 60 3 ./blk_n2su2 blk=0:4,1:4 iprint=0
-$R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./blk_h10sz blk=0:5 iprint=0
+# (.eblk: the same step at the symbolic level — operator infos incl. tensor-product connection infos, expressions)
+$R $D/N2.STO3G.FCIDUMP su2 60 3 ./blk_n2su2 blk=0:4,1:4 eblk=0:4,1:4 iprint=0
+$R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./blk_h10sz blk=0:5 eblk=0:5 iprint=0
+# Cr2/SVP M=250 blocking structures -> *.blkstruct.npz (planfile.write_outer_struct_npz)
+$R $D/CR2.SVP.FCIDUMP su2 250 2 ./bcr2 blk_struct=0:20,1:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true

@@ -164,3 +164,30 @@ def test_host_mirror_records_block_products(built):
         seq.iadd((out, 500, 4, 6), a, 1.0, False, 0.0)
     seq.clear()
     assert seq.n_outer == 0
+
+
+EBLK = sorted(glob.glob(os.path.join(GOLDEN, "blk_*.eblk")))
+
+
+def _sym(fn):
+    return "su2" if "su2" in os.path.basename(fn) else "sz"
+
+
+@pytest.mark.parametrize("fn", EBLK, ids=os.path.basename)
+def test_symbolic_blocking_oracle_result(built, fn):
+    """TensorFunctions::contract -> OperatorFunctions::tensor_product of the host mirror (expressions and tensor-product
+    connection infos from the reference) records block products whose oracle replay gives the reference's enlarged
+    operators; term count == the re-grouped reference list when every Kronecker factor is scalar"""
+    from block2_preview_amd import b2x_host
+    from oracle import oracle
+
+    d = read_arrays(fn)
+    terms_b, _ = b2x_host.symbolic_blocking(_sym(fn), d, False)
+    t = np.frombuffer(bytes(terms_b), OUTER_TERM_DTYPE)
+    assert len(t) > 0
+    v = np.zeros(int(d["meta"][7]))
+    oracle.outer(t, d["site"], d["x"], v)
+    assert np.abs(v - d["v_ref"]).max() <= 1e-12 * max(1.0, np.abs(d["v_ref"]).max())
+    ref_t, _ = load_blk(fn.replace(".eblk", ".blk"))
+    # same number of element-term products as the list recorded by the reference
+    assert int((t["m"].astype(np.int64) * t["n"]).sum()) == int((ref_t["m"].astype(np.int64) * ref_t["n"]).sum())

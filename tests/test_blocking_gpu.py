@@ -109,3 +109,15 @@ def test_cr2_blocking_structure(gpu):
     gpu.outer_build(ar, t, vin, out)
     ar.close()
     assert _close(out, ref)
+
+
+def test_symbolic_blocking_on_device(gpu):
+    """TensorFunctions::contract of the host mirror executed by BatchGEMMSeq::outer_perform == reference operators"""
+    from block2_preview_amd import b2x_host
+    from block2_preview_amd.planfile import read_arrays
+    from test_blocking import EBLK, _sym
+
+    for fn in EBLK:
+        d = read_arrays(fn)
+        _, v = b2x_host.symbolic_blocking(_sym(fn), d, True)
+        assert _close(v, d["v_ref"]), fn
