@@ -364,6 +364,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     uint32_t si = item.seg_begin;
     if (si < item.seg_end) {
         GSeg S = segs[si];
+        GSeg Sn = segs[min(si + 1, item.seg_end - 1)];
         int kb = 0, buf = 0;
         enter(S);
         fetch(S, 0, lds);
@@ -388,7 +389,8 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
             const bool more = nsi < item.seg_end;
             if (early) {
                 if (more && nsi != si) {
-                    S = segs[nsi];
+                    S = Sn; // descriptor prefetched one segment ahead: no scalar-load latency at the switch
+                    Sn = segs[min(nsi + 1, item.seg_end - 1)];
                     enter(S);
                 }
                 if (more)
@@ -399,7 +401,8 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
             __builtin_amdgcn_sched_barrier(0);
             if (!early) {
                 if (more && nsi != si) {
-                    S = segs[nsi];
+                    S = Sn;
+                    Sn = segs[min(nsi + 1, item.seg_end - 1)];
                     enter(S);
                 }
                 if (more)
