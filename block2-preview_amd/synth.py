@@ -149,11 +149,22 @@ def shard_pairs(pairs, rank, world):
     """sum-MPO style sharding of one plan: every operator TERM (here: distinct stage-1 left operator
     block z_off, i.e. one left-block operator of the MPO bond) is owned by exactly one rank, as
     ParallelRuleSimple::index_prefactor assigns integrals (src/dmrg/parallel_simple.hpp:56-99).
-    The partial sigma of all ranks sums to the full H psi."""
+    The partial sigma of all ranks sums to the full H psi.  Owners are chosen by MAC weight (longest processing time
+    first, ties by block order) so that the ranks' H.psi times match; every rank computes the same assignment."""
     if world == 1:
         return pairs
     _, inv = np.unique(pairs["z_off"], return_inverse=True)
-    return pairs[(inv % world) == rank]
+    macs = (pairs["m0"].astype(np.int64) * pairs["n0"] * pairs["k0"] +
+            pairs["m1"].astype(np.int64) * pairs["n1"] * pairs["k1"]).astype(np.float64)
+    wgt = np.bincount(inv, weights=macs)
+    order = np.argsort(-wgt, kind="stable")
+    owner = np.zeros(len(wgt), np.int64)
+    load = np.zeros(world)
+    for i in order:
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += wgt[i]
+    return pairs[owner[inv] == rank]
 
 
 def compact_arena(pairs):
