@@ -348,6 +348,9 @@ struct OpTerm {
     uint8_t dconj = 0;
 };
 
+// which side of op(a) (x) op(b) is the identity and is dropped (perturbative noise; operator_functions.hpp:48)
+enum struct TraceTypes : uint8_t { None = 0, Left = 1, Right = 2 };
+
 template <typename S> struct OperatorFunctions {
     std::shared_ptr<BatchGEMMSeq> seq;
     CG<S> cg;
@@ -400,7 +403,8 @@ template <typename S> struct OperatorFunctions {
     }
     // v[iv] += scale * factor * op(a[ia]) c[ic] op(b[ib])^T for every connection of the matching sub-label
     void tensor_product_multiply(uint8_t conj, const SparseMatrix<S> &a, const SparseMatrix<S> &b,
-                                 const SparseMatrix<S> &c, const SparseMatrix<S> &v, S opdq, double scale = 1.0) const {
+                                 const SparseMatrix<S> &c, const SparseMatrix<S> &v, S opdq, double scale = 1.0,
+                                 TraceTypes tt = TraceTypes::None) const {
         scale = scale * a.factor * b.factor * c.factor;
         if (std::fabs(scale) < 1E-20)
             return;
@@ -414,9 +418,16 @@ template <typename S> struct OperatorFunctions {
         if (ik >= ci.n[conj + 1] || ci.quanta[ik] != abdq)
             throw std::runtime_error("tensor_product_multiply: sub-label not in the connection info");
         int ixa = (int)ci.idx[ik], ixb = ik == ci.n[4] - 1 ? ci.nc : (int)ci.idx[ik + 1];
-        for (int il = ixa; il < ixb; il++)
-            seq->rotate(c[(int)ci.ic[il]], v[(int)ci.stride[il]], a[(int)ci.ia[il]], (conj & 1) ? 3 : 0,
-                        b[(int)ci.ib[il]], (conj & 2) ? 2 : 1, scale * ci.factor[il]);
+        for (int il = ixa; il < ixb; il++) {
+            const GMatrix cm = c[(int)ci.ic[il]], vm = v[(int)ci.stride[il]];
+            if (tt == TraceTypes::None)
+                seq->rotate(cm, vm, a[(int)ci.ia[il]], (conj & 1) ? 3 : 0, b[(int)ci.ib[il]], (conj & 2) ? 2 : 1,
+                            scale * ci.factor[il]);
+            else if (tt == TraceTypes::Left) // v += c . op(b)^T   (operator_functions.hpp:518-526)
+                seq->multiply(cm, false, b[(int)ci.ib[il]], (conj & 2) ? 2 : 1, vm, scale * ci.factor[il], 1.0);
+            else // v += op(a) . c   (:527-535)
+                seq->multiply(a[(int)ci.ia[il]], (conj & 1) ? 3 : 0, cm, false, vm, scale * ci.factor[il], 1.0);
+        }
     }
     // diag(c)[ic] += scale * factor * diag(a[ia]) (x) diag(b[ib])       (operator_functions.hpp:211-245)
     void tensor_product_diagonal(uint8_t conj, const SparseMatrix<S> &a, const SparseMatrix<S> &b,
@@ -475,7 +486,7 @@ template <typename S> struct OperatorFunctions {
     void three_tensor_product_multiply(uint8_t conj, const SparseMatrix<S> &a, const SparseMatrix<S> &b,
                                        const SparseMatrix<S> &c, const SparseMatrix<S> &v, uint8_t dconj,
                                        const SparseMatrix<S> &da, const SparseMatrix<S> &db, bool dleft, S opdq,
-                                       double scale = 1.0) const {
+                                       double scale = 1.0, TraceTypes tt = TraceTypes::None) const {
         scale = scale * a.factor * b.factor * c.factor * da.factor * db.factor;
         if (std::fabs(scale) < 1E-20)
             return;
@@ -501,10 +512,19 @@ template <typename S> struct OperatorFunctions {
             int ja = (int)ci.ia[il], jb = (int)ci.ib[il], jc = (int)ci.ic[il], jv = (int)ci.stride[il];
             uint32_t idc = (uint32_t)(dleft ? ja : jb);
             int idl = (int)(std::lower_bound(di.ic.begin() + idxa, di.ic.begin() + idxb, idc) - di.ic.begin());
-            for (; idl < idxb && di.ic[idl] == idc; idl++)
-                seq->three_rotate(c[jc], v[jv], a[ja], conj & 1, b[jb], !(conj & 2), da[(int)di.ia[idl]], dconj & 1,
-                                  db[(int)di.ib[idl]], (dconj & 2) >> 1, dleft,
-                                  scale * ci.factor[il] * di.factor[idl], di.stride[idl]);
+            for (; idl < idxb && di.ic[idl] == idc; idl++) {
+                const double f = scale * ci.factor[il] * di.factor[idl];
+                const GMatrix dam = da[(int)di.ia[idl]], dbm = db[(int)di.ib[idl]];
+                if (tt == TraceTypes::None)
+                    seq->three_rotate(c[jc], v[jv], a[ja], conj & 1, b[jb], !(conj & 2), dam, dconj & 1, dbm,
+                                      (dconj & 2) >> 1, dleft, f, di.stride[idl]);
+                else if (tt == TraceTypes::Left)
+                    seq->three_rotate_tr_left(c[jc], v[jv], a[ja], conj & 1, b[jb], !(conj & 2), dam, dconj & 1, dbm,
+                                              (dconj & 2) >> 1, dleft, f, di.stride[idl]);
+                else
+                    seq->three_rotate_tr_right(c[jc], v[jv], a[ja], conj & 1, b[jb], !(conj & 2), dam, dconj & 1, dbm,
+                                               (dconj & 2) >> 1, dleft, f, di.stride[idl]);
+            }
         }
     }
 };
@@ -573,6 +593,72 @@ template <typename S> struct TensorFunctions {
                 opf->tensor_product_multiply(t.conj, *lopt.ops[t.a], *ropt.ops[t.b], cmat, vmat, opdq, t.factor);
         }
     }
+    // positions of the identity operator in lopt / ropt and in the two factors of the delayed tensor (-1 = absent)
+    struct IdentityOps {
+        int l = -1, r = -1, dl = -1, dr = -1;
+    };
+    // vmats += (expr with one side traced out) x cmat: the perturbative-noise walk (tensor_functions.hpp:366-803, real
+    // double, no stacked MPO, "reduced" noise: one perturbed wavefunction per target label).  For every term only the
+    // operator of the kept side acts on cmat; the other side must be the identity.  cinfos[j][k] is the connection
+    // info of (psubsl[j], k-th label of cmat.dq + psubsl[j].label), vdqs the sorted target labels of vmats.
+    void tensor_product_partial_multiply(const std::vector<OpTerm> &expr, const OperatorTensor<S> &lopt,
+                                         const OperatorTensor<S> &ropt, bool trace_right, const SparseMatrix<S> &cmat,
+                                         const std::vector<std::pair<uint8_t, S>> &psubsl,
+                                         const std::vector<std::vector<std::shared_ptr<typename SparseMatrixInfo<S>::ConnectionInfo>>> &cinfos,
+                                         const std::vector<S> &vdqs, const std::vector<SparseMatrix<S>> &vmats,
+                                         const IdentityOps &id) const {
+        // no identity on the traced side: the site is not optimised, the noise is skipped (:383-391)
+        if ((!trace_right && id.l < 0) || (trace_right && id.r < 0))
+            return;
+        const bool ldel = lopt.get_type() == OperatorTensorTypes::Delayed, rdel = ropt.get_type() == OperatorTensorTypes::Delayed;
+        const TraceTypes tt = trace_right ? TraceTypes::Right : TraceTypes::Left;
+        for (const OpTerm &t : expr) {
+            const SparseMatrix<S> *dlmat = nullptr, *drmat = nullptr;
+            uint8_t dconj = 0;
+            const bool dleft = ldel; // which tensor is delayed (at most one is)
+            if (ldel || rdel) {
+                const OperatorTensor<S> &dopt = ldel ? lopt : ropt;
+                if (t.type == OpTypes::SumProd && dleft == trace_right) { // the kept operator is the delayed product
+                    dlmat = dopt.lopt->ops[t.d0].get(), drmat = dopt.ropt->ops[t.d1].get(), dconj = t.dconj;
+                } else if (dleft != trace_right) { // the traced identity lives in the delayed tensor
+                    const auto &iop = trace_right ? ropt.ops[id.r] : lopt.ops[id.l];
+                    if (iop->data == nullptr) {
+                        if (id.dl < 0 || id.dr < 0)
+                            throw std::runtime_error("partial multiply: delayed identity factors missing");
+                        dlmat = dopt.lopt->ops[id.dl].get(), drmat = dopt.ropt->ops[id.dr].get();
+                    }
+                }
+            }
+            const SparseMatrix<S> &lmat = trace_right ? *lopt.ops[t.a] : *lopt.ops[id.l];
+            const SparseMatrix<S> &rmat = trace_right ? *ropt.ops[id.r] : *ropt.ops[t.b];
+            const uint8_t cj = trace_right ? (t.conj & 1) : (t.conj & 2);
+            const S q = trace_right ? lmat.info->delta_quantum : rmat.info->delta_quantum;
+            const S opdq = cj ? -q : q;
+            const S pks = cmat.info->delta_quantum + opdq;
+            const std::pair<uint8_t, S> key((uint8_t)(cj ? 1 : 0), opdq);
+            const int ij = (int)(std::lower_bound(psubsl.begin(), psubsl.end(), key,
+                                                  [](const std::pair<uint8_t, S> &x, const std::pair<uint8_t, S> &y) {
+                                                      return x.first != y.first ? x.first < y.first : x.second < y.second;
+                                                  }) -
+                                 psubsl.begin());
+            if (ij >= (int)psubsl.size() || psubsl[ij].first != key.first || psubsl[ij].second != key.second)
+                throw std::runtime_error("partial multiply: operator sub-label not in psubsl");
+            for (int k = 0; k < pks.count(); k++) {
+                const int iv = (int)(std::lower_bound(vdqs.begin(), vdqs.end(), pks[k]) - vdqs.begin());
+                if (iv >= (int)vdqs.size() || vdqs[iv] != pks[k])
+                    throw std::runtime_error("partial multiply: target label not in vdqs");
+                SparseMatrix<S> cm = cmat; // the wavefunction seen through this (sub-label, target) connection info
+                auto cinfo_holder = std::make_shared<SparseMatrixInfo<S>>(*cmat.info);
+                cinfo_holder->cinfo = cinfos[ij][k];
+                cm.info = cinfo_holder;
+                if (dlmat != nullptr)
+                    opf->three_tensor_product_multiply(cj, lmat, rmat, cm, vmats[iv], dconj, *dlmat, *drmat, dleft, opdq,
+                                                       t.factor, tt);
+                else
+                    opf->tensor_product_multiply(cj, lmat, rmat, cm, vmats[iv], opdq, t.factor, tt);
+            }
+        }
+    }
     // diag(mat) += diagonal of expr   (tensor_functions.hpp:2027-2182)
     void tensor_product_diagonal(const std::vector<OpTerm> &expr, const OperatorTensor<S> &lopt,
                                  const OperatorTensor<S> &ropt, const SparseMatrix<S> &mat, S opdq) const {
@@ -632,6 +718,40 @@ template <typename S> struct SymbolicEffectiveHamiltonian {
         std::vector<double> d(ket_info->get_total_memory(), 0.0);
         tf->opf->seq->diag_perform(d.data(), d.size());
         return d;
+    }
+    // Perturbative noise (effective_hamiltonian.hpp:252-423, NoiseTypes::ReducedPerturbative): one perturbed
+    // wavefunction per target label vdqs[i] with info vinfos[i]; builds the connection infos of every
+    // (operator sub-label, target) pair with initialize_wfn (:353-373) and records the single-GEMM list of the partial
+    // multiply into tf->opf->seq.  ket / vdata are the absolute host buffers of psi and of the perturbed
+    // wavefunctions (vmats[i] starts at vdata + voffs[i]); execute with seq->auto_perform(v, ket).
+    void record_perturbative_noise(bool trace_right, const std::vector<std::pair<uint8_t, S>> &psubsl,
+                                   const std::vector<S> &vdqs, const std::vector<std::shared_ptr<Info>> &vinfos,
+                                   const std::vector<uint64_t> &voffs, S vacuum,
+                                   const typename TensorFunctions<S>::IdentityOps &id, double *ket, double *vdata) {
+        const S ket_label = ket_info->delta_quantum, idq = vacuum;
+        std::vector<std::vector<std::shared_ptr<typename Info::ConnectionInfo>>> cinfos(psubsl.size());
+        for (size_t j = 0; j < psubsl.size(); j++) {
+            const S pks = ket_label + psubsl[j].second;
+            cinfos[j].resize(pks.count());
+            for (int k = 0; k < pks.count(); k++) {
+                const int ib = (int)(std::lower_bound(vdqs.begin(), vdqs.end(), pks[k]) - vdqs.begin());
+                if (ib >= (int)vdqs.size() || vdqs[ib] != pks[k])
+                    throw std::runtime_error("perturbative_noise: target label missing");
+                const S odq = psubsl[j].second;
+                std::vector<std::pair<uint8_t, S>> subdq = {
+                    trace_right ? std::make_pair(psubsl[j].first, odq.combine(odq, -idq))
+                                : std::make_pair((uint8_t)(psubsl[j].first << 1), odq.combine(idq, -odq))};
+                cinfos[j][k] = std::make_shared<typename Info::ConnectionInfo>();
+                cinfos[j][k]->initialize_wfn(ket_label, pks[k], odq, subdq, left_op_infos, right_op_infos, ket_info,
+                                             vinfos[ib], tf->opf->cg);
+            }
+        }
+        SparseMatrix<S> cmat;
+        cmat.info = ket_info, cmat.data = ket, cmat.factor = 1.0;
+        std::vector<SparseMatrix<S>> vmats(vinfos.size());
+        for (size_t i = 0; i < vinfos.size(); i++)
+            vmats[i].info = vinfos[i], vmats[i].data = vdata + voffs[i], vmats[i].factor = 1.0;
+        tf->tensor_product_partial_multiply(expr, *lopt, *ropt, trace_right, cmat, psubsl, cinfos, vdqs, vmats, id);
     }
     // record the plan with null-based wavefunctions (every psi / psi' address becomes an element offset)
     void precompute() {

@@ -25,6 +25,7 @@ struct SymEHBase {
     virtual void apply(py::array_t<double, py::array::c_style> b, py::array_t<double, py::array::c_style> c,
                        double factor) = 0;
     virtual py::tuple eigs(std::vector<double> ket, double conv_thrd, int max_iter) = 0;
+    virtual py::tuple perturbative_noise(const py::dict &d, bool execute) = 0;
 };
 
 template <typename S> struct SymEH : SymEHBase {
@@ -147,10 +148,13 @@ template <typename S> struct SymEH : SymEHBase {
                 c++;
             subdq.emplace_back(c, S(sq[k]));
         }
-        size_t nd;
-        const double *dg = arr<double>(d, "diag", &nd);
-        h = std::make_shared<SymbolicEffectiveHamiltonian<S>>(li, ri, lopt, ropt, expr, ket, bra, S(lab[2]), subdq,
-                                                              std::vector<double>(dg, dg + nd));
+        std::vector<double> diag; // (a noise fixture carries no diagonal: only operator(), not eigs, is used on it)
+        if (d.contains("diag")) {
+            size_t nd;
+            const double *dg = arr<double>(d, "diag", &nd);
+            diag.assign(dg, dg + nd);
+        }
+        h = std::make_shared<SymbolicEffectiveHamiltonian<S>>(li, ri, lopt, ropt, expr, ket, bra, S(lab[2]), subdq, diag);
     }
     py::dict wfn_cinfo() const override {
         const auto &c = *h->wfn_info;
@@ -218,6 +222,54 @@ template <typename S> struct SymEH : SymEHBase {
     void apply(py::array_t<double, py::array::c_style> b, py::array_t<double, py::array::c_style> c,
                double factor) override {
         (*h)(GMatrix(b.mutable_data(), (int)b.size(), 1), GMatrix(c.mutable_data(), (int)c.size(), 1), factor);
+    }
+    // perturbative noise from the `noise.*` arrays of an .enoise fixture: returns (b2x_gemm records with operands as
+    // offsets into (arena, psi) and outputs as offsets into the perturbed-wavefunction vector, that vector); with
+    // execute the list also runs on the device (BatchGEMMSeq::auto_perform)
+    py::tuple perturbative_noise(const py::dict &d, bool execute) override {
+        std::map<int, std::shared_ptr<Info>> cache;
+        const int64_t *args = arr<int64_t>(d, "noise.args"), *iop = arr<int64_t>(d, "noise.iop");
+        const bool trace_right = args[0] != 0;
+        size_t np, nv;
+        const int64_t *pc = arr<int64_t>(d, "noise.psubsl.conj", &np);
+        const uint64_t *pl = arr<uint64_t>(d, "noise.psubsl.label");
+        std::vector<std::pair<uint8_t, S>> psubsl;
+        for (size_t i = 0; i < np; i++)
+            psubsl.emplace_back((uint8_t)pc[i], S(pl[i]));
+        const uint64_t *vd = arr<uint64_t>(d, "noise.vdqs", &nv), *vi = arr<uint64_t>(d, "noise.vinfo"),
+                       *vo = arr<uint64_t>(d, "noise.voff");
+        std::vector<S> vdqs;
+        std::vector<std::shared_ptr<Info>> vinfos;
+        std::vector<uint64_t> voffs;
+        for (size_t i = 0; i < nv; i++)
+            vdqs.push_back(S(vd[i])), vinfos.push_back(info(d, (int)vi[i], cache)), voffs.push_back(vo[i]);
+        typename TensorFunctions<S>::IdentityOps id;
+        id.l = (int)iop[0], id.r = (int)iop[1], id.dl = (int)iop[2], id.dr = (int)iop[3];
+        py::array_t<double> psi = py::array_t<double>(py::array::ensure(d["psi"]));
+        py::array_t<double> v((py::ssize_t)args[5]);
+        std::fill(v.mutable_data(), v.mutable_data() + v.size(), 0.0);
+        auto seq = h->tf->opf->seq;
+        seq->gemms.clear(), seq->ga_ptr.clear(), seq->gb_ptr.clear(), seq->gc_ptr.clear(), seq->gemm_nflop = 0;
+        h->record_perturbative_noise(trace_right, psubsl, vdqs, vinfos, voffs, S(arr<uint64_t>(d, "noise.vacuum")[0]), id,
+                                     psi.mutable_data(), v.mutable_data());
+        std::vector<b2x_gemm> g = seq->gemms;
+        for (size_t i = 0; i < g.size(); i++) {
+            auto cls = [&](const double *p, uint8_t &src, uint64_t &off) {
+                if (p >= psi.data() && p < psi.data() + psi.size())
+                    src = 1, off = (uint64_t)(p - psi.data());
+                else
+                    src = 0, off = (uint64_t)(p - arena.data());
+            };
+            cls(seq->ga_ptr[i], g[i].a_src, g[i].a_off), cls(seq->gb_ptr[i], g[i].b_src, g[i].b_off);
+            g[i].c_off = (uint64_t)(seq->gc_ptr[i] - v.data());
+        }
+        py::array_t<uint8_t> ga(g.size() * sizeof(b2x_gemm));
+        std::memcpy(ga.mutable_data(), g.data(), g.size() * sizeof(b2x_gemm));
+        if (execute)
+            seq->auto_perform(GMatrix(v.mutable_data(), (int)v.size(), 1), GMatrix(psi.mutable_data(), (int)psi.size(), 1));
+        else
+            seq->gemms.clear(), seq->ga_ptr.clear(), seq->gb_ptr.clear(), seq->gc_ptr.clear(), seq->gemm_nflop = 0;
+        return py::make_tuple(ga, v);
     }
     py::tuple eigs(std::vector<double> ket, double conv_thrd, int max_iter) override {
         auto r = h->eigs(ket, conv_thrd, max_iter);
@@ -392,6 +444,7 @@ inline void bind_symbolic(py::module_ &m) {
         .def("compute_diag", &SymEHBase::compute_diag)
         .def("diag_terms", &SymEHBase::diag_terms)
         .def("__call__", &SymEHBase::apply, py::arg("b"), py::arg("c"), py::arg("factor") = 1.0)
+        .def("perturbative_noise", &SymEHBase::perturbative_noise, py::arg("fixture"), py::arg("execute") = false)
         .def("eigs", &SymEHBase::eigs, py::arg("ket"), py::arg("conv_thrd") = 5E-6, py::arg("max_iter") = 5000);
     // label algebra exposed for unit tests (packed 64-bit in / out)
     m.def("su2_add", [](uint64_t a, uint64_t b) { return (SU2(a) + SU2(b)).data; });

@@ -17,6 +17,8 @@
  *   eham=<sweep>:<site>[,...]                effective-Hamiltonian level fixtures (infos, tensors, expression)
  *   pnoise=<sweep>:<site>[,...]              single-GEMM list of the perturbative noise (with data + reference result)
  *   pnoise_struct=<sweep>:<site>[,...]       the same list without data
+ *   enoise=<sweep>:<site>[,...]              the perturbative noise at the symbolic level (eham content + sub-labels,
+ *                                            perturbed-wavefunction infos, reference result)
  *   rot=<sweep>:<center>[,...]               environment rotation (TensorFunctions::left_rotate / right_rotate called
  *                                            while MovingEnvironment::center == <center>): GEMM-pair plan + data + result
  *   rot_struct=<sweep>:<center>[,...]        the same plan without data
@@ -38,7 +40,7 @@ using namespace block2;
 using namespace std;
 
 struct DumpSpec {
-    set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct, rot, rot_struct, erot, blk, blk_struct, eblk;
+    set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct, enoise, rot, rot_struct, erot, blk, blk_struct, eblk;
     string prefix;
 };
 
@@ -156,6 +158,12 @@ template <typename S> struct CapTF : TensorFunctions<S, double> {
     mutable vector<double *> pc;
     mutable const double *out_base = nullptr;
     mutable size_t out_len = 0;
+    // arguments of the top-level call (what the symbolic walk consumes)
+    mutable vector<pair<uint8_t, S>> a_psubsl;
+    mutable vector<S> a_vdqs;
+    mutable shared_ptr<SparseMatrixGroup<S, FL>> a_vmats;
+    mutable bool a_trace_right = false;
+    mutable int a_vidx = 0, a_tvidx = 0;
     CapTF(const shared_ptr<OperatorFunctions<S, FL>> &opf) : TensorFunctions<S, FL>(opf) {}
     void tensor_product_partial_multiply(
         const shared_ptr<OpExpr<S>> &expr, const shared_ptr<OpExpr<S>> &xexpr,
@@ -163,6 +171,7 @@ template <typename S> struct CapTF : TensorFunctions<S, double> {
         const shared_ptr<SparseMatrix<S, FL>> &cmat, const vector<pair<uint8_t, S>> &psubsl,
         const vector<vector<shared_ptr<typename SparseMatrixInfo<S>::ConnectionInfo>>> &cinfos, const vector<S> &vdqs,
         const shared_ptr<SparseMatrixGroup<S, FL>> &vmats, int &vidx, int tvidx, bool do_reduce) const override {
+        a_psubsl = psubsl, a_vdqs = vdqs, a_vmats = vmats, a_trace_right = trace_right, a_vidx = vidx, a_tvidx = tvidx;
         TensorFunctions<S, FL>::tensor_product_partial_multiply(expr, xexpr, lopt, ropt, trace_right, cmat, psubsl, cinfos,
                                                                 vdqs, vmats, vidx, tvidx, do_reduce);
         auto b0 = this->opf->seq->batch[0], b1 = this->opf->seq->batch[1];
@@ -621,9 +630,9 @@ template <typename S> struct Dumper : CallbackKernel {
             if (spec.eham.count(key))
                 capture_eham(isw, site);
         } else if (name == "DMRG::sweep::iter.eff_ham.end") {
-            bool wd = spec.pnoise.count(key), st = spec.pnoise_struct.count(key);
-            if (wd || st)
-                capture_pnoise(isw, site, wd);
+            bool wd = spec.pnoise.count(key), st = spec.pnoise_struct.count(key), en = spec.enoise.count(key);
+            if (wd || st || en)
+                capture_pnoise(isw, site, wd, st, en);
         } else if (name == "DMRG::sweep::iter.end") {
             stringstream ss;
             ss.precision(15);
@@ -632,11 +641,14 @@ template <typename S> struct Dumper : CallbackKernel {
         }
     }
 
-    void capture_eham(int isw, int site) const {
-        auto h = dmrg->current_eff_ham;
-        stringstream fn;
-        fn << spec.prefix << ".sw" << isw << ".site" << site << ".eham";
-        EhamDump<S> ed(fn.str());
+    struct EhamOrders {
+        vector<shared_ptr<OpExpr<S>>> l, r, dl, dr;
+        uint64_t arena_len = 0;
+        size_t n_terms = 0;
+    };
+    // everything the symbolic -> numeric layer of one EffectiveHamiltonian consumes (infos, tensors, arena, expression)
+    EhamOrders write_eham_common(EhamDump<S> &ed, const shared_ptr<EffectiveHamiltonian<S, FL>> &h) const {
+        EhamOrders eo;
         ArrayFile &af = ed.af;
         S cdq = h->ket->info->delta_quantum, vdq = h->bra->info->delta_quantum;
         af.u64("labels", vector<uint64_t>{cdq.data, vdq.data, h->opdq.data, h->hop_left_vacuum.data});
@@ -658,9 +670,9 @@ template <typename S> struct Dumper : CallbackKernel {
                    dr = ropt->get_type() == OperatorTensorTypes::Delayed;
         af.u64("tensor.delayed", vector<uint64_t>{(uint64_t)dl, (uint64_t)dr});
         vector<const double *> lp, rp, dlp, drp;
-        auto lorder = ed.put_tensor("lopt", lopt, true, lp);
-        auto rorder = ed.put_tensor("ropt", ropt, true, rp);
-        vector<shared_ptr<OpExpr<S>>> dlorder, drorder;
+        auto &lorder = eo.l, &rorder = eo.r, &dlorder = eo.dl, &drorder = eo.dr;
+        lorder = ed.put_tensor("lopt", lopt, true, lp);
+        rorder = ed.put_tensor("ropt", ropt, true, rp);
         shared_ptr<DelayedOperatorTensor<S, FL>> dopt = nullptr;
         if (dl || dr) {
             dopt = dynamic_pointer_cast<DelayedOperatorTensor<S, FL>>(dl ? lopt : ropt);
@@ -721,6 +733,18 @@ template <typename S> struct Dumper : CallbackKernel {
             add_term(ex);
         af.i64("expr.type", ty), af.i64("expr.conj", cj), af.f64("expr.factor", fac), af.i64("expr.a", ia);
         af.i64("expr.b", ib), af.i64("expr.d0", d0), af.i64("expr.d1", d1), af.i64("expr.dconj", dcj);
+        eo.arena_len = tot, eo.n_terms = ty.size();
+        return eo;
+    }
+    void capture_eham(int isw, int site) const {
+        auto h = dmrg->current_eff_ham;
+        stringstream fn;
+        fn << spec.prefix << ".sw" << isw << ".site" << site << ".eham";
+        EhamDump<S> ed(fn.str());
+        ArrayFile &af = ed.af;
+        EhamOrders eo = write_eham_common(ed, h);
+        uint64_t tot = eo.arena_len;
+        struct { size_t n; size_t size() const { return n; } } ty{eo.n_terms};
         // data: psi, diag, reference sigma
         size_t n = h->ket->total_memory;
         af.f64("psi", h->ket->data, n), af.f64("diag", h->diag->data, n);
@@ -735,7 +759,7 @@ template <typename S> struct Dumper : CallbackKernel {
     }
     // perturbative noise: run the reference's own EffectiveHamiltonian::perturbative_noise with the capturing
     // TensorFunctions swapped in, exactly as DMRG::update_two_dot calls it (src/dmrg/sweep_algorithm.hpp:799-802)
-    void capture_pnoise(int isw, int site, bool with_data) const {
+    void capture_pnoise(int isw, int site, bool with_data, bool structure, bool symbolic) const {
         auto h = dmrg->current_eff_ham;
         auto cap = make_shared<CapTF<S>>(h->tf->opf);
         auto old_tf = h->tf;
@@ -783,6 +807,39 @@ template <typename S> struct Dumper : CallbackKernel {
             g.b_off = g.b_src ? (uint64_t)(cap->pb[i] - ket0) : resolve(cap->pb[i]);
             macs += (uint64_t)g.m * g.n * g.k;
         }
+        if (symbolic) {
+            stringstream efn;
+            efn << spec.prefix << ".sw" << isw << ".site" << site << ".enoise";
+            EhamDump<S> ed(efn.str());
+            ArrayFile &af = ed.af;
+            EhamOrders eo = write_eham_common(ed, h);
+            auto lopt = h->op->lopt, ropt = h->op->ropt;
+            shared_ptr<OpExpr<S>> i_op = make_shared<OpElement<S, FL>>(OpNames::I, SiteIndex(), S());
+            vector<int64_t> iop{EhamDump<S>::find_op(lopt, eo.l, i_op), EhamDump<S>::find_op(ropt, eo.r, i_op), -1, -1};
+            if (lopt->get_type() == OperatorTensorTypes::Delayed || ropt->get_type() == OperatorTensorTypes::Delayed) {
+                auto dopt = dynamic_pointer_cast<DelayedOperatorTensor<S, FL>>(
+                    lopt->get_type() == OperatorTensorTypes::Delayed ? lopt : ropt);
+                iop[2] = EhamDump<S>::find_op(dopt->lopt, eo.dl, i_op), iop[3] = EhamDump<S>::find_op(dopt->ropt, eo.dr, i_op);
+            }
+            af.i64("noise.iop", iop);
+            vector<int64_t> pc;
+            vector<uint64_t> pl, vd, vi, vo;
+            for (auto &x : cap->a_psubsl)
+                pc.push_back(x.first), pl.push_back(x.second.data);
+            for (auto &x : cap->a_vdqs)
+                vd.push_back(x.data);
+            for (int j = 0; j < cap->a_vmats->n; j++)
+                vi.push_back((uint64_t)ed.info_id((*cap->a_vmats)[j]->info, false)), vo.push_back(cap->a_vmats->offsets[j]);
+            af.i64("noise.psubsl.conj", pc), af.u64("noise.psubsl.label", pl), af.u64("noise.vdqs", vd);
+            af.u64("noise.vinfo", vi), af.u64("noise.voff", vo);
+            af.i64("noise.args", vector<int64_t>{(int64_t)cap->a_trace_right, (int64_t)cap->a_vidx, (int64_t)cap->a_tvidx,
+                                                 (int64_t)n, (int64_t)macs, (int64_t)cap->out_len});
+            af.u64("noise.vacuum", vector<uint64_t>{dmrg->me->ket->info->vacuum.data});
+            af.f64("psi", h->ket->data, h->ket->total_memory);
+            af.f64("out_ref", pket->data, pket->total_memory);
+            cerr << "ENOISE " << efn.str() << " gemms=" << n << endl;
+        }
+        if (with_data || structure) {
         stringstream fn;
         fn << spec.prefix << ".sw" << isw << ".site" << site << (with_data ? ".pnoise" : ".pnoise_struct");
         {
@@ -808,6 +865,7 @@ template <typename S> struct Dumper : CallbackKernel {
            << " kets=" << pket->n << " arena=" << tot << " macs=" << macs;
         log.push_back(ss.str());
         cerr << ss.str() << endl;
+        }
         pket->deallocate_infos();
         pket->deallocate();
     }
@@ -1018,6 +1076,8 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
         dumper->spec.pnoise = parse_pairs(kv["pnoise"]);
     if (kv.count("pnoise_struct"))
         dumper->spec.pnoise_struct = parse_pairs(kv["pnoise_struct"]);
+    if (kv.count("enoise"))
+        dumper->spec.enoise = parse_pairs(kv["enoise"]);
     if (kv.count("rot"))
         dumper->spec.rot = parse_pairs(kv["rot"]);
     if (kv.count("rot_struct"))

@@ -24,8 +24,9 @@ $R $D/H10.STO6G.R1.8.FCIDUMP sz 30 4 ./e_h10sz eham=0:5,1:4 iprint=0
 # perturbative-noise fixtures: the single-GEMM list EffectiveHamiltonian::perturbative_noise records
 # (captured through a TensorFunctions subclass, oracle/ref_dump.cpp capture_pnoise), its operands and the perturbed
 # wavefunctions the reference returned; sweep 0 runs forward (TraceTypes::Right), sweep 1 backward (TraceTypes::Left)
-$R $D/N2.STO3G.FCIDUMP su2 60 3 ./p_n2su2 pnoise=0:3,1:5 iprint=0
-$R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./p_h10sz pnoise=0:5,1:4 iprint=0
+# (.enoise: the same step at the symbolic level — the eham content plus operator sub-labels, perturbed-ket infos, result)
+$R $D/N2.STO3G.FCIDUMP su2 60 3 ./p_n2su2 pnoise=0:3,1:5 enoise=0:3,1:5 iprint=0
+$R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./p_h10sz pnoise=0:5,1:4 enoise=1:4 iprint=0
 # Cr2/SVP M=250 noise lists, structure only; converted to .pnoise_struct.npz by
 #   python -c "from block2_preview_amd.planfile import *; write_gemm_struct_npz(out, read_gemm_list(in))"
 $R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2m250 pnoise_struct=0:20,1:20,1:10 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true

@@ -190,3 +190,26 @@ def test_host_mirror_records_noise_gemms(built):
                               3 * 6 + 3)
     assert seq2.gemm_dims()[1] == (0, 1, 3, 8, 8, 8, 8, 8, 1.0)
     assert seq2.n_gemms == 2
+
+
+ENOISE = sorted(glob.glob(os.path.join(GOLDEN, "*.enoise")))
+
+
+@pytest.mark.parametrize("fn", ENOISE, ids=os.path.basename)
+def test_symbolic_perturbative_noise(built, fn):
+    """SymbolicEffectiveHamiltonian::perturbative_noise of the host mirror (initialize_wfn per (sub-label, target),
+    tensor_product_partial_multiply walk, TraceTypes variants of (three_)tensor_product_multiply) records as many GEMMs
+    and MACs as the reference did and its oracle replay gives the reference's perturbed wavefunctions"""
+    from block2_preview_amd import b2x_host
+    from block2_preview_amd.planfile import GEMM_DTYPE, read_arrays
+    from oracle import oracle
+
+    d = read_arrays(fn)
+    h = b2x_host.SymbolicEffectiveHamiltonian("su2" if "su2" in os.path.basename(fn) else "sz", d)
+    gb, _ = h.perturbative_noise(d, False)
+    g = np.frombuffer(bytes(gb), GEMM_DTYPE)
+    assert len(g) == int(d["noise.args"][3])
+    out = np.zeros(int(d["noise.args"][5]))
+    macs = oracle.gemm_list(g, d["arena"], d["psi"], out)
+    assert macs == int(d["noise.args"][4])
+    assert np.abs(out - d["out_ref"]).max() <= 1e-12 * max(1.0, np.abs(d["out_ref"]).max())
