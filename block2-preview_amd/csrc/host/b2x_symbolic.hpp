@@ -17,6 +17,9 @@
 // OpExpr tree — the tree belongs to the MPO layer, which is out of scope.  Host-only integer / 9j work; the
 // numerics run on the device through BatchGEMMSeq (b2x_host.hpp).
 #pragma once
+#include <fstream>
+#include <istream>
+#include <ostream>
 #include "b2x_host.hpp"
 #include <cstring>
 #include <map>
@@ -306,6 +309,49 @@ template <typename S> struct SparseMatrixInfo {
     bool is_fermion = false, is_wavefunction = false;
     int n = 0;
     std::shared_ptr<ConnectionInfo> cinfo;
+    // on-disk layout of the reference (src/core/sparse_matrix.hpp:511-566, ubond_t = uint16_t): delta quantum (8 B), n
+    // (int32), then one uint32 array [quanta: 2 words each | n_states_bra, n_states_ket: uint16 each | n_states_total:
+    // uint32 each], then is_fermion and is_wavefunction (1 B each).  Byte-compatible in both directions.
+    void load_data(std::istream &ifs) {
+        uint64_t dq;
+        int32_t nn;
+        ifs.read((char *)&dq, sizeof(dq)), ifs.read((char *)&nn, sizeof(nn));
+        if (!ifs.good() || nn < 0)
+            throw std::runtime_error("SparseMatrixInfo::load_data failed.");
+        delta_quantum = S(dq), n = nn;
+        std::vector<uint32_t> buf((size_t)n * 4);
+        ifs.read((char *)buf.data(), (std::streamsize)(buf.size() * 4));
+        quanta.resize(n), n_states_bra.resize(n), n_states_ket.resize(n), n_states_total.resize(n);
+        const uint16_t *bk = (const uint16_t *)(buf.data() + (size_t)n * 2);
+        for (int i = 0; i < n; i++) {
+            quanta[i] = S((uint64_t)buf[2 * i] | ((uint64_t)buf[2 * i + 1] << 32));
+            n_states_bra[i] = bk[i], n_states_ket[i] = bk[n + i];
+            n_states_total[i] = buf[(size_t)n * 3 + i];
+        }
+        uint8_t f, w;
+        ifs.read((char *)&f, 1), ifs.read((char *)&w, 1);
+        if (ifs.fail())
+            throw std::runtime_error("SparseMatrixInfo::load_data failed.");
+        is_fermion = f != 0, is_wavefunction = w != 0;
+        cinfo = nullptr;
+    }
+    void save_data(std::ostream &ofs) const {
+        uint64_t dq = delta_quantum.data;
+        int32_t nn = n;
+        ofs.write((const char *)&dq, sizeof(dq)), ofs.write((const char *)&nn, sizeof(nn));
+        std::vector<uint32_t> buf((size_t)n * 4, 0);
+        uint16_t *bk = (uint16_t *)(buf.data() + (size_t)n * 2);
+        for (int i = 0; i < n; i++) {
+            buf[2 * i] = (uint32_t)(quanta[i].data & 0xFFFFFFFFu), buf[2 * i + 1] = (uint32_t)(quanta[i].data >> 32);
+            if (n_states_bra[i] > 0xFFFF || n_states_ket[i] > 0xFFFF)
+                throw std::runtime_error("SparseMatrixInfo::save_data: bond dimension exceeds ubond_t (uint16)");
+            bk[i] = (uint16_t)n_states_bra[i], bk[n + i] = (uint16_t)n_states_ket[i];
+            buf[(size_t)n * 3 + i] = n_states_total[i];
+        }
+        ofs.write((const char *)buf.data(), (std::streamsize)(buf.size() * 4));
+        uint8_t f = is_fermion, w = is_wavefunction;
+        ofs.write((const char *)&f, 1), ofs.write((const char *)&w, 1);
+    }
     int find_state(S q) const {
         auto it = std::lower_bound(quanta.begin(), quanta.end(), q);
         return (it == quanta.end() || *it != q) ? -1 : (int)(it - quanta.begin());
@@ -320,6 +366,40 @@ template <typename S> struct SparseMatrix {
     double *data = nullptr;
     double factor = 1.0;
     size_t total_memory = 0;
+    std::vector<double> storage; // owns the data of a matrix loaded from disk
+    // on-disk layout of the reference (src/core/sparse_matrix.hpp:896-971, uncompressed): [info if load_info] factor
+    // (f64), total_memory (size_t), data.  The compressed variant (FPCodec, total_memory == SIZE_MAX flag) is refused.
+    void load_data(const std::string &filename, bool load_info = false) {
+        std::ifstream ifs(filename.c_str(), std::ios::binary);
+        if (!ifs.good())
+            throw std::runtime_error("SparseMatrix:load_data on '" + filename + "' failed.");
+        if (load_info) {
+            info = std::make_shared<SparseMatrixInfo<S>>();
+            info->load_data(ifs);
+        }
+        uint64_t tm;
+        ifs.read((char *)&factor, sizeof(factor)), ifs.read((char *)&tm, sizeof(tm));
+        if (tm == ~(uint64_t)0)
+            throw std::runtime_error("SparseMatrix:load_data on '" + filename + "': compressed storage is not supported");
+        total_memory = (size_t)tm;
+        storage.resize(total_memory);
+        ifs.read((char *)storage.data(), (std::streamsize)(total_memory * sizeof(double)));
+        if (ifs.fail() || ifs.bad())
+            throw std::runtime_error("SparseMatrix:load_data on '" + filename + "' failed.");
+        data = storage.data();
+    }
+    void save_data(const std::string &filename, bool save_info = false) const {
+        std::ofstream ofs(filename.c_str(), std::ios::binary);
+        if (!ofs.good())
+            throw std::runtime_error("SparseMatrix:save_data on '" + filename + "' failed.");
+        if (save_info)
+            info->save_data(ofs);
+        uint64_t tm = total_memory;
+        ofs.write((const char *)&factor, sizeof(factor)), ofs.write((const char *)&tm, sizeof(tm));
+        ofs.write((const char *)data, (std::streamsize)(total_memory * sizeof(double)));
+        if (!ofs.good())
+            throw std::runtime_error("SparseMatrix:save_data on '" + filename + "' failed.");
+    }
     GMatrix operator[](int i) const {
         return GMatrix(data + info->n_states_total[i], (int)info->n_states_bra[i], (int)info->n_states_ket[i]);
     }

@@ -411,7 +411,48 @@ template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
     return py::make_tuple(pa, v);
 }
 
+// SparseMatrix on-disk format of the reference (MPS tensors, operator blocks): load -> dict of arrays, and save
+template <typename S> py::dict sm_load(const std::string &fn) {
+    SparseMatrix<S> m;
+    m.load_data(fn, true);
+    py::dict r;
+    std::vector<uint64_t> q;
+    for (auto x : m.info->quanta)
+        q.push_back(x.data);
+    r["quanta"] = q, r["nbra"] = m.info->n_states_bra, r["nket"] = m.info->n_states_ket, r["ntot"] = m.info->n_states_total;
+    r["meta"] = std::vector<uint64_t>{m.info->delta_quantum.data, (uint64_t)m.info->is_fermion,
+                                      (uint64_t)m.info->is_wavefunction, (uint64_t)m.total_memory};
+    r["factor"] = m.factor;
+    r["data"] = py::array_t<double>(m.total_memory, m.data);
+    return r;
+}
+template <typename S>
+void sm_save(const std::string &fn, const std::vector<uint64_t> &q, const std::vector<uint32_t> &nb,
+             const std::vector<uint32_t> &nk, const std::vector<uint32_t> &nt, const std::vector<uint64_t> &meta, double factor,
+             py::array_t<double, py::array::c_style> data) {
+    SparseMatrix<S> m;
+    m.info = std::make_shared<SparseMatrixInfo<S>>();
+    m.info->n = (int)q.size();
+    for (auto x : q)
+        m.info->quanta.push_back(S(x));
+    m.info->n_states_bra = nb, m.info->n_states_ket = nk, m.info->n_states_total = nt;
+    m.info->delta_quantum = S(meta[0]), m.info->is_fermion = meta[1] != 0, m.info->is_wavefunction = meta[2] != 0;
+    m.factor = factor, m.total_memory = (size_t)data.size(), m.data = data.mutable_data();
+    m.save_data(fn, true);
+}
+
 inline void bind_symbolic(py::module_ &m) {
+    m.def("sparse_matrix_load", [](const std::string &sym, const std::string &fn) {
+        return sym == "su2" ? sm_load<SU2>(fn) : sm_load<SZ>(fn);
+    });
+    m.def("sparse_matrix_save", [](const std::string &sym, const std::string &fn, std::vector<uint64_t> q, std::vector<uint32_t> nb,
+                                   std::vector<uint32_t> nk, std::vector<uint32_t> nt, std::vector<uint64_t> meta, double factor,
+                                   py::array_t<double, py::array::c_style> data) {
+        if (sym == "su2")
+            sm_save<SU2>(fn, q, nb, nk, nt, meta, factor, data);
+        else
+            sm_save<SZ>(fn, q, nb, nk, nt, meta, factor, data);
+    });
     m.def("symbolic_blocking", [](const std::string &sym, const py::dict &d, bool execute) {
         if (sym == "sz")
             return sym_blocking<SZ>(d, execute);

@@ -28,6 +28,9 @@
  *   blk_struct=<sweep>:<center>[,...]        the same terms without data
  *   eblk=<sweep>:<center>[,...]              blocking at the symbolic level (operator infos incl. the tensor-product
  *                                            connection infos, the expression of every enlarged operator, data)
+ *   tensor_file=<i>[,<j>...]                 after the run: MPS tensor i written by the reference's own
+ *                                            SparseMatrix::save_data(file, true) (src/core/sparse_matrix.hpp:957-971) next to
+ *                                            its content as named arrays (on-disk format fixture)
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
  */
 #include "block2_core.hpp"
@@ -1103,6 +1106,21 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     double energy = dmrg->solve(n_sweeps, mps->center == 0, tol);
     double tt = t.get_time();
     callback_() = make_shared<CallbackKernel>();
+    if (kv.count("tensor_file"))
+        for (auto &tok : Parsing::split(kv["tensor_file"], ",", true)) {
+            int i = Parsing::to_int(tok);
+            mps->load_tensor(i);
+            auto t = mps->tensors[i];
+            string fn = prefix + ".mps" + tok + ".tensor";
+            t->save_data(fn, true); // info + factor + total_memory + data, as MPS::save_tensor writes it (mps.hpp:2573-2578)
+            EhamDump<S> ed(fn + ".arr");
+            int id = ed.info_id(t->info, false);
+            ed.af.f64("factor", vector<double>{t->factor});
+            ed.af.u64("info", vector<uint64_t>{(uint64_t)id, (uint64_t)t->total_memory});
+            ed.af.f64("data", t->data, t->total_memory);
+            cerr << "TENSOR " << fn << " n=" << t->info->n << " len=" << t->total_memory << endl;
+            mps->unload_tensor(i);
+        }
     ofstream lf((prefix + ".log").c_str());
     lf.precision(15);
     for (auto &l : dumper->log)

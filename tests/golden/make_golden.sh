@@ -45,3 +45,7 @@ $R $D/N2.STO3G.FCIDUMP su2 60 3 ./blk_n2su2 blk=0:4,1:4 eblk=0:4,1:4 iprint=0
 $R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./blk_h10sz blk=0:5 eblk=0:5 iprint=0
 # Cr2/SVP M=250 blocking structures -> *.blkstruct.npz (planfile.write_outer_struct_npz)
 $R $D/CR2.SVP.FCIDUMP su2 250 2 ./bcr2 blk_struct=0:20,1:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
+# on-disk format fixtures: MPS tensors written by the reference's own SparseMatrix::save_data(file, true)
+# next to their content as named arrays (.arr)
+$R $D/N2.STO3G.FCIDUMP su2 60 2 ./disk_n2su2 tensor_file=3,6 iprint=0
+$R $D/H10.STO6G.R1.8.FCIDUMP sz 30 2 ./disk_h10sz tensor_file=4 iprint=0
