@@ -87,6 +87,41 @@ def device_sync():
     check(lib().b2x_device_sync())
 
 
+class DeviceBuffer:
+    """fp64 device vector from b2x_device_alloc (16-byte read slack included, see b2x_plan_execute)"""
+
+    def __init__(self, n, host=None):
+        p = C.c_void_p()
+        check(lib().b2x_device_alloc(C.byref(p), C.c_size_t(max(1, n) * 8)))
+        self.ptr, self.n = p.value, n
+        if host is None:
+            host = np.zeros(n)
+        self.upload(host)
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host, np.float64)
+        assert host.size == self.n
+        if self.n:
+            check(lib().b2x_memcpy_h2d(C.c_void_p(self.ptr), _ptr(host), C.c_size_t(self.n * 8)))
+
+    def download(self):
+        out = np.empty(self.n)
+        if self.n:
+            check(lib().b2x_memcpy_d2h(_ptr(out), C.c_void_p(self.ptr), C.c_size_t(self.n * 8)))
+        return out
+
+    def close(self):
+        if self.ptr:
+            lib().b2x_device_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Arena:
     """Operator blocks resident in HBM (OperatorTensor::ops[*]->data of the reference)."""
 

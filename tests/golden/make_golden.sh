@@ -33,16 +33,17 @@ $R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2m250 pnoise_struct=0:20,1:20,1:10 occ=$D/CR
 # environment-rotation fixtures: the GEMM pairs the reference's own tensor_rotate records (Auto mode)
 # for TensorFunctions::left_rotate / right_rotate, the enlarged operators, the MPS tensor and the rotated operators the
 # reference computed (.plan), plus the same step at the symbolic level (.erot: operator infos, MPS tensor infos)
-$R $D/N2.STO3G.FCIDUMP su2 60 3 ./rot_n2su2 rot=0:4,1:4 erot=0:4,1:4 iprint=0
-$R $D/H10.STO6G.R1.8.FCIDUMP sz 40 3 ./rot_h10sz rot=0:5,1:4 erot=0:5 iprint=0
+# (rotation and blocking fixtures come from ONE run per molecule, see the blocking entry below, so that the enlarged
+#  operators the blocking step produces are exactly the rotation's input: tests chain them on the device)
 # Cr2/SVP M=250 rotation structures -> *.rotstruct.npz (write_struct_npz)
 $R $D/CR2.SVP.FCIDUMP su2 250 2 ./rcr2 rot_struct=0:20,1:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
 # blocking fixtures: the element-wise block-product terms re-grouped from the k = 1 GEMM groups the
 # reference's own TensorFunctions::tensor_product records (Auto mode) for left_contract / right_contract, the block and
 # site operators and the enlarged operators the reference computed
 # (.eblk: the same step at the symbolic level — operator infos incl. tensor-product connection infos, expressions)
-$R $D/N2.STO3G.FCIDUMP su2 60 3 ./blk_n2su2 blk=0:4,1:4 eblk=0:4,1:4 iprint=0
-$R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./blk_h10sz blk=0:5 eblk=0:5 iprint=0
+$R $D/N2.STO3G.FCIDUMP su2 60 3 ./x_n2su2 blk=0:4,1:4 eblk=0:4,1:4 rot=0:4,1:4 erot=0:4,1:4 iprint=0
+$R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./x_h10sz blk=0:5 eblk=0:5 rot=0:5,1:4 erot=0:5 iprint=0
+for f in x_*; do case $f in *blk*) n=blk_${f#x_};; *rot*) n=rot_${f#x_};; *) n=lcr_${f#x_};; esac; mv $f $n; done
 # Cr2/SVP M=250 blocking structures -> *.blkstruct.npz (planfile.write_outer_struct_npz)
 $R $D/CR2.SVP.FCIDUMP su2 250 2 ./bcr2 blk_struct=0:20,1:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
 # on-disk format fixtures: MPS tensors written by the reference's own SparseMatrix::save_data(file, true)

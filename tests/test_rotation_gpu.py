@@ -41,3 +41,42 @@ def test_cr2_rotation_structure(gpu, fn, f):
     plan.close(), arena.close()
     assert st["macs"] == pf.macs
     assert np.abs(out - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def _chain_pairs():
+    out = []
+    for blk in sorted(glob.glob(os.path.join(GOLDEN, "blk_*.blk"))):
+        rot = blk.replace("blk_", "rot_", 1).replace("blk.blk", "rot.plan")
+        if os.path.exists(rot):
+            out.append((blk, rot))
+    return out
+
+
+@pytest.mark.parametrize("blk,rot", _chain_pairs(), ids=lambda x: os.path.basename(x))
+def test_left_contract_rotate_device_resident(gpu, blk, rot):
+    """MovingEnvironment::left_contract_rotate / right_contract_rotate (src/dmrg/moving_environment.hpp:226-420) as one
+    device-resident chain: blocking writes the enlarged operators into an HBM vector, the rotation plan reads that very
+    vector as its psi and writes the rotated operators to HBM; only the final result is downloaded and compared with
+    the rotated operators the reference computed (both fixtures come from ONE reference run, so the reference's
+    enlarged operators are exactly the rotation's input)."""
+    from block2_preview_amd.planfile import OUTER_TERM_DTYPE, read_plan
+
+    d = read_arrays(blk)
+    terms = np.frombuffer(d["terms"].tobytes(), OUTER_TERM_DTYPE)
+    pf = read_plan(rot)
+    assert pf.psi_len == int(d["lens"][3])
+    site_ops = gpu.Arena.from_host([d["arena"]])
+    block_ops = gpu.DeviceBuffer(len(d["in"]), d["in"])
+    enlarged = gpu.DeviceBuffer(pf.psi_len)
+    gpu.outer_build(site_ops, terms, block_ops.ptr, enlarged.ptr, True, len(d["in"]), pf.psi_len)
+    mps = gpu.Arena.from_host([pf.arena])
+    plan = gpu.Plan(mps, pf.pairs, pf.psi_len, pf.sigma_len)
+    rotated = gpu.DeviceBuffer(pf.sigma_len)
+    plan.execute_device(enlarged.ptr, rotated.ptr, 1.0)
+    gpu.device_sync()
+    out = rotated.download()
+    assert np.abs(out - pf.sigma_ref).max() <= 1e-12 * max(1.0, np.abs(pf.sigma_ref).max())
+    # and the intermediate really is the reference's enlarged block
+    assert np.abs(enlarged.download() - d["out_ref"]).max() <= 1e-12 * max(1.0, np.abs(d["out_ref"]).max())
+    for x in (plan, mps, site_ops, block_ops, enlarged, rotated):
+        x.close()
