@@ -371,11 +371,12 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         commit();
         bool cur_kmaj = s_kmaj;
         __syncthreads(); // drains the DMA (vmcnt(0)) and publishes the image
-        // Stagger the SIMD partners (waves w and w + NW/2 run on the same SIMD with the same program and one barrier
-        // per chunk): the first half of the waves issues the next chunk's loads BEFORE the MFMA block, the second half
-        // in the MIDDLE of it, so one partner's address arithmetic / load issue overlaps the other's MFMAs instead of
-        // leaving the matrix pipe idle in both (MI355X_MICROARCH.md, wave-stagger note).
-        const bool early = wave < NW / 2;
+        // SIMD partners must not run in lockstep (same program, same barrier: both would issue loads, then both MFMAs,
+        // leaving the matrix pipe idle in the load phase of both).  With 4-wave workgroups (the shipped configuration)
+        // a SIMD's two waves belong to two DIFFERENT workgroups with independent barriers and drift apart by
+        // themselves.  With 8-wave workgroups (waves w and w + 4 share a SIMD) the second half of the waves issues the
+        // next chunk's loads in the MIDDLE of the MFMA block instead of before it (MI355X_MICROARCH.md, stagger note).
+        const bool early = NW < 8 || wave < NW / 2;
         constexpr int KH = KS / 2;
         using H0 = std::integral_constant<int, 0>;
         using H1 = std::integral_constant<int, KH>;
@@ -439,25 +440,31 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
 }
 
 // One launch per stage: every workgroup picks the body specialised for its item's tile height (one body per number
-// of 16-row fragments, 1..16), so tiles of all heights share a grid (no per-variant launch tails) and one LDS
+// of 16-row fragments, 1..kGGTileM/16), so tiles of all heights share a grid (no per-variant launch tails) and one LDS
 // allocation, and no MFMA is issued on padding rows beyond the last fragment.
+// Shipped configuration: 128 x 128 tiles, 4 waves x (8 row fragments x 2 column fragments) = 128 accumulator VGPRs per
+// wave, 32 KB of LDS: TWO workgroups per CU (one wave of each per SIMD).  Against the earlier 256 x 128 / 8-wave /
+// CF = 1 workgroup (one per CU) this halves the ds_reads per MFMA (an A fragment feeds two MFMAs), gives the SIMD
+// partners independent barriers, and wastes less on the many sectors shorter than 256 rows:
+// M=1000 26.2 -> 29.6, M=4000 52.3 -> 55.2 TFLOP/s on the bench plan, 62.3 on uniform 1024^3 pairs.
 template <int CF, int NW, int KC, bool SB>
 __global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
                                                          const double *__restrict__ arena,
                                                          const double *__restrict__ psi, double *__restrict__ scratch,
                                                          double *__restrict__ slabs) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * 256 * KC];
+    __shared__ __attribute__((aligned(16))) double lds[2 * kGGTileM * KC];
     const GItem item = items[blockIdx.x];
 #define B2X_GG_CASE(T)                                                                                                 \
     case T:                                                                                                            \
-        gg_body<T, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);                                       \
+        if constexpr (T * 16 <= kGGTileM)                                                                              \
+            gg_body<T, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);                                   \
         break;
     switch ((item.rows + 15) >> 4) { // row fragments of the tile
         B2X_GG_CASE(1) B2X_GG_CASE(2) B2X_GG_CASE(3) B2X_GG_CASE(4) B2X_GG_CASE(5) B2X_GG_CASE(6) B2X_GG_CASE(7)
         B2X_GG_CASE(8) B2X_GG_CASE(9) B2X_GG_CASE(10) B2X_GG_CASE(11) B2X_GG_CASE(12) B2X_GG_CASE(13) B2X_GG_CASE(14)
         B2X_GG_CASE(15)
     default:
-        gg_body<16, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<kGGTileM / 16, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
     }
 #undef B2X_GG_CASE
 }
@@ -712,10 +719,10 @@ hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_beg
     // chunk depth 16: a 32-deep chunk halves the barriers (+2 % on uniform 1024^3 pairs) but pads every K to 32 and
     // spills at 256 VGPRs (-2 % on the M=4000 plan)
     if (seg_scaled)
-        hipLaunchKernelGGL((gg_kernel<1, kGGTileN / 16, 16, true>), dim3(n), dim3(kGGTileN * 4), 0, st, segs,
+        hipLaunchKernelGGL((gg_kernel<kGGCF, kGGTileN / (16 * kGGCF), 16, true>), dim3(n), dim3(kGGTileN * 4 / kGGCF), 0, st, segs,
                            items + v_begin[0], arena, psi, scratch, slabs);
     else
-        hipLaunchKernelGGL((gg_kernel<1, kGGTileN / 16, 16, false>), dim3(n), dim3(kGGTileN * 4), 0, st, segs,
+        hipLaunchKernelGGL((gg_kernel<kGGCF, kGGTileN / (16 * kGGCF), 16, false>), dim3(n), dim3(kGGTileN * 4 / kGGCF), 0, st, segs,
                            items + v_begin[0], arena, psi, scratch, slabs);
     return hipGetLastError();
 }

@@ -80,7 +80,9 @@ struct SuperStep {
     uint32_t tile_begin, tile_end; // DTile range (two-stage tile list)
 };
 
-static const int kGGTileM = 256, kGGTileN = 128;
+// tile of one workgroup of the grouped-GEMM kernel: kGGTileN / (16 * kGGCF) waves, each kGGCF column fragments wide
+static const int kGGTileM = 128, kGGTileN = 128;
+static const int kGGCF = 2;
 static const int kGGRowUnit = 16; // tile heights are multiples of one MFMA row fragment
 
 // kernel classes of the fused path.  nw = tile width / 16, tmf = tile height / 16, k1f = k1 chunk / 16.
