@@ -5,7 +5,8 @@
 //                           accumulator IS the stage-1 B operand (C/D layout row = (lane>>4) + 4*reg, col = lane&15
 //                           equals the B-fragment layout of k-step `reg`), so W never leaves the register file
 //                           (the reference round-trips it through a per-thread work array, batch_gemm.hpp:1630-1635)
-//   gg_kernel<CF,NW,KC>     grouped GEMM of the two-stage path (tall sectors): LDS-DMA staged A, register B
+//   gg_kernel<CF,NW,KC,SB>  grouped GEMM of the two-stage path (tall sectors) and of single-GEMM lists: LDS-DMA staged A,
+//                           register B; shipped as <2,4,16>: 128x128 tiles, 4 waves, two workgroups per CU
 //   hpsi_reduce             psi'[tile] += scale * sum of the tile's partial slabs, fixed order (no atomics)
 //   hpsi_generic            per-pair atomic kernel: on-device cross-check / fallback for unsegmentable plans
 //   diag_build_k, vec_*     diagonal of H_eff and BLAS-1 for the device-resident Davidson
@@ -199,8 +200,8 @@ __global__ __launch_bounds__(256, 2) void hpsi_wave(const DPart *__restrict__ pa
 }
 
 // ------------------------------------------------------------------------------------------------
-// gg_kernel<TMF, CF, NW>: grouped GEMM of the two-stage path (large sectors).  One workgroup of NW waves
-// (two per SIMD) owns a (TMF*16) x (NW*CF*16) output tile and walks a list of K-segments
+// gg_body<TMF, CF, NW, KC, SB>: grouped GEMM of the two-stage path (large sectors) and of single-GEMM lists.  One
+// workgroup of NW waves owns a (TMF*16) x (NW*CF*16) output tile and walks a list of K-segments
 //     C[window] += A(mr x K) * B(K x nc).
 //   stage 0 items: one segment, A = X (psi), B = op(Y) (arena), tile stored (x alpha) into the W scratch
 //   stage 1 items: many segments, A = op(Z) (arena), B = W (scratch), tile stored into a partial slab
