@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tile-n", type=int, default=0)
     ap.add_argument("--item-macs", type=int, default=0)
+    ap.add_argument("--tile-m", type=int, default=0, help="tallest sector kept on the fused wave kernel (0 = default)")
+    ap.add_argument("--two-stage", type=int, default=0, help="0 auto, 1 all sectors through the grouped-GEMM path, -1 never")
     ap.add_argument("--scratch-mb", type=int, default=0, help="W scratch budget of the two-stage path (MiB, 0 = default)")
     return ap.parse_args()
 
@@ -174,7 +176,7 @@ def main():
     sigma_t = torch.zeros(full.sigma_len, dtype=torch.float64, device=dev)
     arena = capi.Arena.adopt_device(arena_t.data_ptr(), arena_len, keep=arena_t)
     plan = capi.Plan(arena, mine, full.psi_len, full.sigma_len, tile_n=args.tile_n, item_macs=args.item_macs,
-                     scratch_mb=args.scratch_mb)
+                     scratch_mb=args.scratch_mb, two_stage=args.two_stage, tile_m=args.tile_m)
     st = plan.stats
     log("compiled in %.1f s: %s" % (time.time() - t0, st))
     stream = torch.cuda.current_stream().cuda_stream

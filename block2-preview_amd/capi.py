@@ -170,11 +170,12 @@ class Arena:
 class Plan:
     """Device-resident GEMM-pair plan (BatchGEMMSeq after precompute(), before post_precompute())."""
 
-    def __init__(self, arena, pairs, psi_len, sigma_len, kernel=0, tile_n=0, item_macs=0, two_stage=0, scratch_mb=0):
+    def __init__(self, arena, pairs, psi_len, sigma_len, kernel=0, tile_n=0, item_macs=0, two_stage=0, scratch_mb=0,
+                 tile_m=0):
         pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
         opt = PlanOptions()
         opt.kernel, opt.tile_n, opt.item_macs = kernel, tile_n, item_macs
-        opt.two_stage, opt.scratch_mb = two_stage, scratch_mb
+        opt.two_stage, opt.scratch_mb, opt.tile_m = two_stage, scratch_mb, tile_m
         h = C.c_void_p()
         check(lib().b2x_plan_create(C.byref(h), arena._h, C.c_size_t(len(pairs)), _ptr(pairs), C.c_size_t(psi_len),
                                     C.c_size_t(sigma_len), C.byref(opt)))

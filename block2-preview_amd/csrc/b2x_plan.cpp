@@ -190,13 +190,36 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     std::vector<HostTile> htiles;
     std::vector<const Component *> big; // components routed to the two-stage path
     const int two_stage = opt ? opt->two_stage : 0;
+    struct SectorShape {
+        bool must;
+        double macs;
+    };
+    std::vector<SectorShape> shapes(comps.size());
+    bool any_must = false;
+    const double fused_macs = opt && opt->tile_m > 0 ? 1e8 * opt->tile_m : 2e8;
+    for (size_t ci = 0; ci < comps.size(); ci++) {
+        const Component &c = comps[ci];
+        int max_k0 = 0;
+        double sector_macs = 0;
+        for (uint32_t wi = c.w_begin; wi < c.w_end; wi++) {
+            const b2x_pair &p = pairs[win[wi].pair];
+            max_k0 = std::max(max_k0, (int)p.k0);
+            sector_macs += (double)p.m0 * p.n0 * p.k0 + (double)p.m1 * p.n1 * p.k1;
+        }
+        shapes[ci].must = c.rows > 128 || c.cols > 128 || max_k0 > 512;
+        shapes[ci].macs = sector_macs;
+        any_must = any_must || shapes[ci].must;
+    }
     for (const Component &c : comps) {
         // auto routing: the fused kernel recomputes stage 0 per row tile and keeps W in registers, which
         // pays for sectors that fit one tile; tall / wide / deep ones go to the grouped-GEMM path
-        int max_k0 = 0;
-        for (uint32_t wi = c.w_begin; wi < c.w_end; wi++)
-            max_k0 = std::max(max_k0, (int)pairs[win[wi].pair].k0);
-        const bool large = c.rows > 128 || c.cols > 128 || max_k0 > 512;
+        const SectorShape &sh = shapes[&c - comps.data()];
+        // Sectors taller / wider / deeper than one fused tile must take the grouped-GEMM path.  When a plan has such
+        // sectors it pays that path's fixed costs anyway (three more launches, the W round trip), and then every sector
+        // with real work runs its MFMAs better there; a plan without them (M <= 250 on the Cr2 structure) stays fused
+        // (measured on the bench plan: M=250 2.2 ms all fused vs 3.6 ms all grouped; M=500 8.1 -> 6.9 ms and M=1000
+        // 21.7 -> 20.7 ms with this rule).
+        const bool large = sh.must || (any_must && sh.macs > fused_macs);
         if (two_stage > 0 || (two_stage == 0 && large)) {
             big.push_back(&c);
             continue;
