@@ -46,8 +46,10 @@ __global__ __launch_bounds__(256, 2) void hpsi_wave(const DPart *__restrict__ pa
         for (int q = 0; q < CF; q++)
             acc[f][q] = v4d{0.0, 0.0, 0.0, 0.0};
 
+    DPart Pn = parts[item.part_begin]; // descriptors are prefetched one part ahead (scalar loads)
     for (uint32_t pi = item.part_begin; pi < item.part_end; pi++) {
-        const DPart P = parts[pi];
+        const DPart P = Pn;
+        Pn = parts[min(pi + 1, item.part_end - 1)];
         const int k0 = P.k0, mr = P.mr, nc = P.nc, tr0 = P.tr0, tc0 = P.tc0;
         const int f_lo = tr0 >> 4, f_hi = (tr0 + mr + 15) >> 4;
         // per-lane column of every column fragment (clamped offset + validity)

@@ -295,8 +295,19 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     }
     st.n_tiles = out.tiles.size();
     // work-item size: aim for ~16 items per CU, but never below ~0.5 MMAC-equivalents
-    double item_cost = opt && opt->item_macs > 0 ? (double)opt->item_macs : std::max((double)total_cost / 4096.0, 524288.0);
-    const double step_item_cost = opt && opt->item_macs > 0 ? (double)opt->item_macs : 6.0e7;
+    // Work-item sizes.  Every item writes a partial slab of its tile that hpsi_reduce has to read back, so more items
+    // than the chip can run at once only buy tail balance at the price of reduce traffic (at M=250 the reduce was 38 %
+    // of an H.psi with 32 768 wave items: 2.2 ms; ~10 000 items: 1.75 ms; ~4 000: 2.6 ms, too few to balance).  Fused
+    // classes: about three wave items per wave slot (256 CUs x 4 SIMDs x 3-4 waves).  Grouped GEMM: enough workgroup items for ~8 rounds over the 512 workgroup
+    // slots, between 2e6 (small plans need the parallelism) and 6e7 (large plans: fewer, longer items amortise the
+    // tile store) MFMA-slot units.
+    double gg_macs_total = 0;
+    for (size_t ci = 0; ci < comps.size(); ci++)
+        if (two_stage > 0 || (two_stage == 0 && (shapes[ci].must || (any_must && shapes[ci].macs > fused_macs))))
+            gg_macs_total += shapes[ci].macs;
+    const bool forced = opt && opt->item_macs > 0;
+    const double item_cost = forced ? (double)opt->item_macs : std::max((double)total_cost / 10240.0, 131072.0);
+    const double step_item_cost = forced ? (double)opt->item_macs : std::min(6.0e7, std::max(2.0e6, gg_macs_total / 4096.0));
     uint64_t slab = 0;
     for (size_t t = 0; t < htiles.size(); t++) {
         HostTile &ht = htiles[t];
@@ -307,8 +318,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         if (ht.parts.empty())
             continue;
         double tile_cost = std::accumulate(ht.cost.begin(), ht.cost.end(), 0.0);
-        // a wave-kernel item occupies one wave, not a workgroup: aim for 8x more of them
-        const double ic = kClasses[ht.cls].wave ? std::max(item_cost / 8.0, 65536.0) : item_cost;
+        const double ic = forced ? std::max(item_cost / 8.0, 65536.0) : item_cost; // (forced: test knob, 1/8 per wave item)
         int n_it = std::max(1, (int)std::lround(tile_cost / ic));
         double per = tile_cost / n_it, acc = 0;
         uint32_t pb = (uint32_t)cw.parts.size(), begin = pb;
