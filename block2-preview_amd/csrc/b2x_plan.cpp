@@ -618,7 +618,8 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     }
     st.n_targets = comps.size();
     const int TN = kGGTileN;
-    const double per_item = opt && opt->item_macs > 0 ? (double)opt->item_macs : 6.0e7;
+    // item size as in compile_plan: ~8 rounds over the workgroup slots, between 2e6 and 6e7 MFMA-slot units
+    const double per_item = opt && opt->item_macs > 0 ? (double)opt->item_macs : std::min(6.0e7, std::max(2.0e6, (double)st.macs / 4096.0));
     SuperStep ss{};
     uint64_t slab = 0, gg_macs = 0;
     for (const Component &c : comps) {
