@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <numeric>
 
 namespace b2x {
@@ -193,21 +194,24 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     struct SectorShape {
         bool must;
         double macs;
+        int max_k;
     };
     std::vector<SectorShape> shapes(comps.size());
     bool any_must = false;
     const double fused_macs = opt && opt->tile_m > 0 ? 1e8 * opt->tile_m : 2e8;
+    const int kdeep = 64; // inner dimensions beyond this run better through LDS-staged chunks than in the wave kernel
     for (size_t ci = 0; ci < comps.size(); ci++) {
         const Component &c = comps[ci];
-        int max_k0 = 0;
+        int max_k0 = 0, max_k = 0;
         double sector_macs = 0;
         for (uint32_t wi = c.w_begin; wi < c.w_end; wi++) {
             const b2x_pair &p = pairs[win[wi].pair];
             max_k0 = std::max(max_k0, (int)p.k0);
+            max_k = std::max(max_k, std::max((int)p.k0, (int)p.k1));
             sector_macs += (double)p.m0 * p.n0 * p.k0 + (double)p.m1 * p.n1 * p.k1;
         }
         shapes[ci].must = c.rows > 128 || c.cols > 128 || max_k0 > 512;
-        shapes[ci].macs = sector_macs;
+        shapes[ci].macs = sector_macs, shapes[ci].max_k = max_k;
         any_must = any_must || shapes[ci].must;
     }
     for (const Component &c : comps) {
@@ -218,8 +222,9 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         // sectors it pays that path's fixed costs anyway (three more launches, the W round trip), and then every sector
         // with real work runs its MFMAs better there; a plan without them (M <= 250 on the Cr2 structure) stays fused
         // (measured on the bench plan: M=250 2.2 ms all fused vs 3.6 ms all grouped; M=500 8.1 -> 6.9 ms and M=1000
-        // 21.7 -> 20.7 ms with this rule).
-        const bool large = sh.must || (any_must && sh.macs > fused_macs);
+        // 21.7 -> 20.7 ms with this rule).  "Real work" = many MACs in the sector or a deep inner dimension (the
+        // rotation plans have thousands of one-pair sectors with k of several hundred: M=1000 4.9 -> 3.5 ms).
+        const bool large = sh.must || (any_must && (sh.macs > fused_macs || sh.max_k > kdeep));
         if (two_stage > 0 || (two_stage == 0 && large)) {
             big.push_back(&c);
             continue;
@@ -303,7 +308,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     // tile store) MFMA-slot units.
     double gg_macs_total = 0;
     for (size_t ci = 0; ci < comps.size(); ci++)
-        if (two_stage > 0 || (two_stage == 0 && (shapes[ci].must || (any_must && shapes[ci].macs > fused_macs))))
+        if (two_stage > 0 || (two_stage == 0 && (shapes[ci].must || (any_must && (shapes[ci].macs > fused_macs || shapes[ci].max_k > kdeep)))))
             gg_macs_total += shapes[ci].macs;
     const bool forced = opt && opt->item_macs > 0;
     const double item_cost = forced ? (double)opt->item_macs : std::max((double)total_cost / 10240.0, 131072.0);
