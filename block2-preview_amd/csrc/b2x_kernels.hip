@@ -282,7 +282,8 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     uint32_t bmask = 0;
     bool bmasked = false;
     // issue the DMA of the A chunk at k offset kb into LDS buffer `As`, and the B loads into bnxt
-    auto fetch = [&](const GSeg &S, int kb, double *As) __attribute__((always_inline)) {
+    // the A half of a fetch: this wave's share of the chunk's LDS-DMA
+    auto fetch_dma = [&](int kb, double *As) __attribute__((always_inline)) {
         const uint32_t kbo = (uint32_t)kb * astep;
 #pragma unroll
         for (int j = 0; j < NI; j++) {
@@ -293,6 +294,9 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
                                                  16, 0, 0);
             }
         }
+    };
+    auto fetch = [&](const GSeg &S, int kb, double *As) __attribute__((always_inline)) {
+        fetch_dma(kb, As);
         const uint32_t bstep = (uint32_t)S.b_sk;
 #pragma unroll
         for (int q = 0; q < CF; q++) {
@@ -364,6 +368,38 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         pin_schedule(nsc);
     };
 
+    // A wave whose columns all lie beyond the tile's width (the last column tile of a sector is cut at 32-column wave
+    // granularity) only helps staging the A chunks: same segment walk and the same barriers as its workgroup, but no B
+    // loads and no MFMAs, so its SIMD is left to the wave of the other workgroup on the CU.  The branch is taken once,
+    // before the main loop, so the MFMA path below stays one straight loop.
+    if (wave * (CF * 16) >= item.cols) {
+        uint32_t hi = item.seg_begin;
+        if (hi < item.seg_end) {
+            GSeg S = segs[hi];
+            int kb = 0, buf = 0;
+            enter(S);
+            fetch_dma(0, lds);
+            __syncthreads();
+            while (true) {
+                uint32_t nsi = hi;
+                int nkb = kb + KC;
+                if (nkb >= S.K)
+                    nsi = hi + 1, nkb = 0;
+                const bool more = nsi < item.seg_end;
+                if (more && nsi != hi) {
+                    S = segs[nsi];
+                    enter(S);
+                }
+                if (!more)
+                    break;
+                fetch_dma(nkb, lds + (buf ^ 1) * ABUF);
+                buf ^= 1;
+                __syncthreads();
+                hi = nsi, kb = nkb;
+            }
+        }
+        return;
+    }
     uint32_t si = item.seg_begin;
     if (si < item.seg_end) {
         GSeg S = segs[si];

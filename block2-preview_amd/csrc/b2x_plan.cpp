@@ -38,6 +38,17 @@ std::vector<int> balanced_cuts(int total, int max_piece) {
     return cuts;
 }
 
+// Column cuts for the grouped-GEMM kernel: full tiles plus one remainder tile.  A wave covers kGGTileN / NW columns and a
+// wave without columns issues no MFMA, so the remainder tile costs only the waves it fills (balanced tiles would keep
+// more waves busy on padding).
+std::vector<int> wave_cuts(int total, int tile) {
+    std::vector<int> cuts;
+    for (int s = 0; s < total; s += tile)
+        cuts.push_back(s);
+    cuts.push_back(total);
+    return cuts;
+}
+
 // Row cuts for the grouped-GEMM kernel, which has a body for every tile height that is a multiple of 16 rows
 // (<= 256): split `total` into ceil(U/16) pieces of near-equal size in units of 16 (U = ceil(total/16)), so the
 // issued rows are 16*U (the minimum) and no piece is needlessly small.
@@ -376,7 +387,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             // stage 0: tiles of every W
             for (const PW &pw : cur) {
                 const b2x_pair &p = pairs[win[pw.wi].pair];
-                std::vector<int> rc = unit_cuts(p.k1), cc = balanced_cuts(p.n0, TN);
+                std::vector<int> rc = unit_cuts(p.k1), cc = wave_cuts(p.n0, TN);
                 for (size_t a = 0; a + 1 < rc.size(); a++)
                     for (size_t b = 0; b + 1 < cc.size(); b++) {
                         GSeg g{};
@@ -424,7 +435,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         rc.push_back(bounds[bi] + sub[k]);
                 }
                 rc.push_back(c.rows);
-                std::vector<int> cc = balanced_cuts(c.cols, TN);
+                std::vector<int> cc = wave_cuts(c.cols, TN);
                 int nrt = (int)rc.size() - 1, nct = (int)cc.size() - 1;
                 std::vector<std::vector<GSeg>> tsegs((size_t)nrt * nct);
                 std::vector<double> tcost((size_t)nrt * nct, 0.0);
@@ -519,7 +530,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 const GItem &it = out.gitems[ii];
                 uint64_t tm = (uint64_t)kGGRowUnit * (uint64_t)(variant(it) + 1);
                 for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
-                    st.macs_issued += tm * TN * (uint64_t)round_up(out.gsegs[k].K, 16);
+                    st.macs_issued += tm * (uint64_t)round_up(it.cols, 16 * kGGCF) * (uint64_t)round_up(out.gsegs[k].K, 16);
             }
             out.steps.push_back(ss);
             out.scratch_elems = std::max(out.scratch_elems, used);
@@ -642,7 +653,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
                 rc.push_back(bounds[bi] + sub[k]);
         }
         rc.push_back(c.rows);
-        std::vector<int> cc = balanced_cuts(c.cols, TN);
+        std::vector<int> cc = wave_cuts(c.cols, TN);
         const int nrt = (int)rc.size() - 1, nct = (int)cc.size() - 1;
         std::vector<std::vector<GSeg>> tsegs((size_t)nrt * nct);
         std::vector<double> tcost((size_t)nrt * nct, 0.0);
@@ -729,7 +740,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     for (const GItem &it : out.gitems) {
         uint64_t tm = (uint64_t)kGGRowUnit * (uint64_t)(variant(it) + 1);
         for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
-            st.macs_issued += tm * TN * (uint64_t)round_up(out.gsegs[k].K, 16);
+            st.macs_issued += tm * (uint64_t)round_up(it.cols, 16 * kGGCF) * (uint64_t)round_up(out.gsegs[k].K, 16);
     }
     out.steps.push_back(ss);
     out.gslab_elems = slab;
