@@ -14,6 +14,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The full-size GPU tests generate their data on the device with torch.  torch must load and initialise ITS HIP
+    # runtime before libb2x.so pulls in the system one (the other order leaves torch without a device), so when the GPU
+    # tests are selected torch is imported here, before any fixture touches libb2x.
+    expr = config.getoption("markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr:
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
 
 
 def golden_plan_files():

@@ -144,3 +144,78 @@ def test_auto_routing_mixed_paths(gpu):
     oracle.replay(big.pairs, big.arena, big.psi, ref, 1.0, 8)
     sig, st = _run(gpu, big)
     assert _close(sig, ref), st
+
+
+def test_edge_cases(gpu):
+    """empty plan, 1x1x1 pair, leading dimensions larger than the rows, a pair deeper than the fused path takes (k0 > 512)"""
+    from block2_preview_amd.planfile import PAIR_DTYPE
+
+    arena = gpu.Arena.from_host([np.arange(1.0, 5000.0)])
+    plan = gpu.Plan(arena, np.zeros(0, PAIR_DTYPE), 7, 5)
+    sig = np.full(5, 3.0)
+    plan.execute_host(np.ones(7), sig, 2.0)
+    assert np.array_equal(sig, np.full(5, 3.0)) and plan.stats["macs"] == 0
+    plan.close()
+    p = np.zeros(3, PAIR_DTYPE)
+    # 1 x 1 x 1:  v[2] += 0.5 * z * (x * y)
+    p[0] = (1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 1.0, 0.5, 3, 10, 20, 2)
+    # 3x2 block of psi with lda 5, op(Y) = Y^T (2x4 stored 4x2, ldb 3), Z 2x3 with lda 4, window of sigma with ldc 6
+    p[1] = (3, 4, 2, 5, 3, 2, 4, 3, 4, 6, 0, 1, 0, 0, 0, 1.5, -1.0, 10, 100, 200, 10)
+    # deep pair: k0 = 600 (> 512) goes through the grouped-GEMM path
+    p[2] = (5, 3, 600, 600, 3, 4, 3, 5, 5, 3, 0, 0, 0, 0, 0, 1.0, 1.0, 40, 300, 2400, 40)
+    rng = np.random.default_rng(12)
+    psi_len, sigma_len = 40 + 5 * 600, 60
+    psi = rng.random(psi_len)
+    arena_h = rng.random(5000)
+    ar = gpu.Arena.from_host([arena_h])
+    plan = gpu.Plan(ar, p, psi_len, sigma_len)
+    sig = rng.random(sigma_len)
+    ref = sig.copy()
+    oracle.replay(p, arena_h, psi, ref, 0.25, 1)
+    plan.execute_host(psi, sig, 0.25)
+    assert _close(sig, ref)
+    assert plan.stats["macs_issued"] > 0  # the deep pair took the two-stage path
+    plan.close(), ar.close(), arena.close()
+
+
+def test_full_size_m4000_properties(gpu):
+    """BASELINE size (the bench workload: Cr2 plan x16 -> M=4000, 98 722 pairs, 20.7 TMAC, 73 GB of operators): the oracle
+    cannot visit it, so the MFMA path is checked through size-independent properties: linearity in psi, bitwise
+    repeatability, and agreement with the independent per-pair atomic kernel (hpsi_generic) on the same device data."""
+    import torch
+
+    from block2_preview_amd.planfile import read_struct_npz
+
+    base = read_struct_npz(os.path.join(os.path.dirname(FILES[0]), "cr2_su2_m250_sw1_site20.struct.npz"))
+    full = synth.scale_plan(base, 16)
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    arena_t = torch.empty(full.arena_len + 8, dtype=torch.float64, device=dev)
+    for a in range(0, full.arena_len, 1 << 28):
+        arena_t[a:a + (1 << 28)].uniform_(-0.5, 0.5, generator=g)
+    x = torch.empty(full.psi_len + 8, dtype=torch.float64, device=dev).uniform_(-0.5, 0.5, generator=g)
+    y = torch.empty(full.psi_len + 8, dtype=torch.float64, device=dev).uniform_(-0.5, 0.5, generator=g)
+    z = 0.3 * x - 1.7 * y
+    arena = gpu.Arena.adopt_device(arena_t.data_ptr(), full.arena_len, keep=arena_t)
+    plan = gpu.Plan(arena, full.pairs, full.psi_len, full.sigma_len)
+    assert plan.stats["macs"] == full.macs
+    s = torch.cuda.current_stream().cuda_stream
+
+    def apply(v, **kw):
+        out = torch.zeros(full.sigma_len, dtype=torch.float64, device=dev)
+        plan.execute_device(v.data_ptr(), out.data_ptr(), 1.0, s)
+        torch.cuda.synchronize()
+        return out
+
+    hx, hy, hz = apply(x), apply(y), apply(z)
+    scale = float(hz.abs().max())
+    assert float((hz - (0.3 * hx - 1.7 * hy)).abs().max()) <= 1e-11 * scale
+    assert torch.equal(apply(x), hx)  # fixed summation order
+    plan.close()
+    generic = gpu.Plan(arena, full.pairs, full.psi_len, full.sigma_len, kernel=1)
+    out = torch.zeros(full.sigma_len, dtype=torch.float64, device=dev)
+    generic.execute_device(x.data_ptr(), out.data_ptr(), 1.0, s)
+    torch.cuda.synchronize()
+    assert float((out - hx).abs().max()) <= 1e-10 * float(hx.abs().max())
+    generic.close(), arena.close()
