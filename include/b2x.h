@@ -75,7 +75,8 @@ typedef struct b2x_plan_stats {
     uint64_t n_items;         /* work items (tile x pair-chunk) launched per execute */
     uint64_t n_parts;         /* (pair x tile) parts */
     uint64_t device_bytes;    /* plan metadata + partial-sum slabs resident in HBM */
-    uint64_t macs_executed;   /* MACs the tiled kernels really issue (>= macs: stage 0 is recomputed per row tile) */
+    uint64_t macs_executed;   /* MACs the kernels really execute: > macs where the fused kernel recomputes stage 0 per row
+                                 tile, < macs where the cheaper association of a pair is taken (keep_order = 0) */
     uint64_t dominant_class;  /* kernel class that carries most MACs */
     uint64_t macs_dominant;   /* MACs executed by the dominant class */
     uint64_t macs_alg_dominant; /* algorithmic (reference-count) MACs of the pairs in the dominant class */
@@ -90,7 +91,9 @@ typedef struct b2x_plan_options {
     int64_t item_macs;            /* target MACs per work item (0 = auto) */
     int32_t two_stage;            /* 0 = auto (sectors taller than one fused tile), 1 = always, -1 = never */
     int32_t scratch_mb;           /* W scratch budget of the two-stage path in MiB (0 = 16384) */
-    int32_t reserved[6];
+    int32_t keep_order;           /* 1 = always form X.op(Y) first, as the reference does; 0 = per pair the cheaper of
+                                     (op(Z).X).op(Y) and op(Z).(X.op(Y)) (same result up to rounding) */
+    int32_t reserved[5];
 } b2x_plan_options;
 
 const char *b2x_last_error(void);

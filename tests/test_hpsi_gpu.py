@@ -118,8 +118,11 @@ def test_config1_scale_h10_m500(gpu):
 def test_golden_two_stage_path(gpu, fn):
     """the grouped-GEMM (two-stage, W through scratch) path on the reference's golden plans"""
     pf = read_plan(fn)
-    sig, st = _run(gpu, pf, two_stage=1)
+    sig, st = _run(gpu, pf, two_stage=1, keep_order=1)
     assert st["macs_issued"] > 0 and st["macs_executed"] == st["macs"]
+    assert _close(sig, pf.sigma_ref)
+    sig, st = _run(gpu, pf, two_stage=1)  # per pair the cheaper of (op(Z) X) op(Y) and op(Z) (X op(Y))
+    assert st["macs_executed"] <= st["macs"]
     assert _close(sig, pf.sigma_ref)
 
 
