@@ -12,6 +12,14 @@ left-operator blocks and only their data), each rank replays its share and the p
 with ONE all-reduce (RCCL over xGMI) per step — strong scaling, as ParallelTensorFunctions::operator()
 does with MPI (src/core/parallel_tensor_functions.hpp:51-55).
 
+`value` and `roofline.achieved` count the ALGORITHMIC flops of the workload, 2 x the reference's nflop (SURVEY.md
+§8d: 2 * sum over pairs of m0 n0 k0 + m1 n1 k1, the reference's order of operations).  The plan compiler executes
+fewer: per pair it takes the cheaper association of op(Z).X.op(Y) and it computes a stage-0 product shared by several
+pairs once (`roofline.executed_over_algorithmic_macs`, 0.66 on this plan; same result up to rounding, nothing is cached
+across steps).  `roofline.executed_tflops` / `frac_executed` are what the matrix cores really sustain — the hardware
+roofline fraction; `achieved` / `frac` can therefore exceed the MFMA peak.  `--keep-order 1` replays the reference's
+order pair by pair (executed == algorithmic).
+
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around the dominant kernel;
 `cpu_baseline` replays a bounded sample of the same plan on the host cores, with the reference's own
 BatchGEMMSeq executor (oracle/_ref/ref_replay, kind "reference") when that binary travelled with the repo,
@@ -239,7 +247,8 @@ def main():
                          "executed_over_algorithmic_macs": round(st["macs_executed"] / max(1, st["macs"]), 3),
                          # what the matrix cores really sustain: the plan compiler takes, per pair, the cheaper of
                          # (op(Z).X).op(Y) and op(Z).(X.op(Y)), so fewer MACs run than the reference's order counts
-                         "executed_tflops": round(2.0 * st["macs_dominant"] / (k_ms * 1e-3) / 1e12, 3)},
+                         "executed_tflops": round(2.0 * st["macs_dominant"] / (k_ms * 1e-3) / 1e12, 3),
+                         "frac_executed": round(2.0 * st["macs_dominant"] / (k_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4)},
             "sigma_checksum": checksum,
         }
         if world == 1 and not args.no_cpu:

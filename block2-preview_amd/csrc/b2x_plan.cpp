@@ -377,11 +377,19 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         // k1 k0 n + m1 k1 n (on the Cr2 mid-chain plan 42 % of the pairs flip and 24 % of the MACs disappear; the result
         // differs from the reference's by rounding only).  flip: stage 0 writes W' = alpha op(Z) X (m1 x k0) to the scratch,
         // stage 1 accumulates W' . op(Y).
+        // Pairs that share the stage-0 product (same X slice and same right operator block for W, same left operator
+        // block and same X slice for W') compute it ONCE per super-step: the shared W is stored unscaled and every
+        // pair's alpha is applied per segment in stage 1 (the SCALED kernel variant).  On the Cr2 mid-chain plan 29 % of
+        // the pairs reuse a product of another pair (H = sum of left (x) right operator products: many left operators meet
+        // the same right operator), another 13 % of the MACs.  To bring the sharers into one super-step the pairs are
+        // processed in the order of their stage-0 key, not of their psi' sector (hpsi_reduce adds the slabs of every
+        // super-step into psi', so a sector may be spread over super-steps).
         struct PW {
             const Component *c;
             uint32_t wi;
             uint64_t w_off;
             bool flip;
+            bool owner; // generates the stage-0 items of its W
         };
         const bool allow_flip = !(opt && opt->keep_order == 1);
         auto flipped = [&](const b2x_pair &p) {
@@ -399,7 +407,9 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             // stage 0: tiles of every W
             for (const PW &pw : cur) {
                 const b2x_pair &p = pairs[win[pw.wi].pair];
-                if (pw.flip) { // W'(m1 x k0) = alpha * op(Z)(m1 x k1) . X(k1 x k0)
+                if (!pw.owner)
+                    continue;
+                if (pw.flip) { // W'(m1 x k0) = op(Z)(m1 x k1) . X(k1 x k0)
                     std::vector<int> rc = unit_cuts(p.m1), cc = wave_cuts(p.k0, TN);
                     for (size_t a = 0; a + 1 < rc.size(); a++)
                         for (size_t b = 0; b + 1 < cc.size(); b++) {
@@ -415,7 +425,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             GItem it{};
                             it.seg_begin = (uint32_t)out.gsegs.size(), it.seg_end = it.seg_begin + 1;
                             it.out_off = pw.w_off + (uint64_t)rc[a] * p.k0 + cc[b], it.out_ld = p.k0;
-                            it.rows = g.mr, it.cols = g.nc, it.alpha = p.alpha0 * p.alpha1, it.out_kind = 1;
+                            it.rows = g.mr, it.cols = g.nc, it.alpha = 1.0, it.out_kind = 1;
                             out.gsegs.push_back(g);
                             out.gitems.push_back(it);
                             gg_macs += (uint64_t)g.mr * g.nc * g.K;
@@ -437,7 +447,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         GItem it{};
                         it.seg_begin = (uint32_t)out.gsegs.size(), it.seg_end = it.seg_begin + 1;
                         it.out_off = pw.w_off + (uint64_t)rc[a] * p.n0 + cc[b], it.out_ld = p.n0;
-                        it.rows = g.mr, it.cols = g.nc, it.alpha = p.alpha0 * p.alpha1, it.out_kind = 1;
+                        it.rows = g.mr, it.cols = g.nc, it.alpha = 1.0, it.out_kind = 1;
                         out.gsegs.push_back(g);
                         out.gitems.push_back(it);
                         gg_macs += (uint64_t)g.mr * g.nc * g.K;
@@ -447,6 +457,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             ss.tile_begin = (uint32_t)out.gtiles.size();
             // stage 1: per component, per psi' tile, the segments of this step's pairs
             uint64_t slab = 0;
+            // (the step's pairs arrive in stage-0 key order: regroup them by psi' sector, plan order inside a sector)
+            std::stable_sort(cur.begin(), cur.end(), [](const PW &x, const PW &y) {
+                return x.c != y.c ? x.c < y.c : x.wi < y.wi;
+            });
             size_t i = 0;
             while (i < cur.size()) {
                 size_t j = i;
@@ -494,7 +508,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                                     g.b_off = p.y_off + (uint64_t)c_lo * p.ldb0, g.b_sk = 1, g.b_sc = p.ldb0;
                                 else
                                     g.b_off = p.y_off + (uint64_t)c_lo, g.b_sk = p.ldb0, g.b_sc = 1;
-                                g.K = p.k0, g.alpha = 1.0;
+                                g.K = p.k0, g.alpha = p.alpha0 * p.alpha1;
                             } else {
                             g.a_src = 0;
                             if (p.ta1)
@@ -502,7 +516,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             else
                                 g.a_off = p.z_off + (uint64_t)r_lo * p.lda1, g.a_sr = p.lda1, g.a_sk = 1;
                             g.b_src = 2, g.b_off = cur[q].w_off + (uint64_t)c_lo, g.b_sk = p.n0, g.b_sc = 1;
-                            g.K = p.k1, g.alpha = 1.0;
+                            g.K = p.k1, g.alpha = p.alpha0 * p.alpha1;
                             }
                             g.mr = rb - ra, g.nc = cb - ca;
                             g.tc0 = ca - cc[b]; // (ra == rc[a]: rows are cut at every window boundary)
@@ -583,16 +597,52 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             cur.clear();
             used = 0;
         };
+        struct Cand {
+            const Component *c;
+            uint32_t wi;
+            bool flip;
+            uint64_t key[7]; // identifies the stage-0 product
+        };
+        std::vector<Cand> cand;
         for (const Component *c : big)
             for (uint32_t wi = c->w_begin; wi < c->w_end; wi++) {
                 const b2x_pair &p = pairs[win[wi].pair];
-                const bool fl = flipped(p);
-                uint64_t wsz = ((fl ? (uint64_t)p.m1 * p.k0 : (uint64_t)p.k1 * p.n0) + 1) & ~(uint64_t)1;
-                if (used + wsz > budget && !cur.empty())
-                    flush();
-                cur.push_back(PW{c, wi, used, fl});
-                used += wsz;
+                Cand cd{};
+                cd.c = c, cd.wi = wi, cd.flip = flipped(p);
+                if (cd.flip) // W' = op(Z) X: left operator block + psi slice
+                    cd.key[0] = 1, cd.key[1] = p.x_off, cd.key[2] = p.z_off,
+                    cd.key[3] = ((uint64_t)p.m1 << 32) | (uint32_t)p.k1, cd.key[4] = ((uint64_t)p.k0 << 32) | (uint32_t)p.lda0,
+                    cd.key[5] = ((uint64_t)p.lda1 << 8) | p.ta1, cd.key[6] = 0;
+                else // W = X op(Y): psi slice + right operator block
+                    cd.key[0] = 0, cd.key[1] = p.x_off, cd.key[2] = p.y_off,
+                    cd.key[3] = ((uint64_t)p.k1 << 32) | (uint32_t)p.k0, cd.key[4] = ((uint64_t)p.n0 << 32) | (uint32_t)p.lda0,
+                    cd.key[5] = ((uint64_t)p.ldb0 << 8) | p.tb0, cd.key[6] = 0;
+                cand.push_back(cd);
             }
+        auto key_less = [](const Cand &x, const Cand &y) {
+            for (int k = 0; k < 7; k++)
+                if (x.key[k] != y.key[k])
+                    return x.key[k] < y.key[k];
+            return false;
+        };
+        if (allow_flip) // (keep_order = 1 replays the reference pair by pair: sector order, no sharing)
+            std::stable_sort(cand.begin(), cand.end(), key_less);
+        uint64_t last_off = 0;
+        for (size_t q = 0; q < cand.size(); q++) {
+            const Cand &cd = cand[q];
+            const b2x_pair &p = pairs[win[cd.wi].pair];
+            const bool same = allow_flip && q > 0 && !cur.empty() && !key_less(cand[q - 1], cd) && !key_less(cd, cand[q - 1]);
+            if (same) { // shares the product of the previous pair (still in this super-step)
+                cur.push_back(PW{cd.c, cd.wi, last_off, cd.flip, false});
+                continue;
+            }
+            uint64_t wsz = ((cd.flip ? (uint64_t)p.m1 * p.k0 : (uint64_t)p.k1 * p.n0) + 1) & ~(uint64_t)1;
+            if (used + wsz > budget && !cur.empty())
+                flush();
+            cur.push_back(PW{cd.c, cd.wi, used, cd.flip, true});
+            last_off = used;
+            used += wsz;
+        }
         flush();
         st.n_tiles += out.gtiles.size();
         st.n_items += out.gitems.size();
@@ -603,6 +653,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         if (cls_macs[k] > cls_macs[st.dominant_class])
             st.dominant_class = k;
     }
+    out.seg_scaled = true; // stage-1 segments carry their pair's alpha (shared stage-0 products are stored unscaled)
     st.macs_executed = cls_macs[0] + cls_macs[1] + cls_macs[2] + gg_macs;
     st.macs_dominant = cls_macs[st.dominant_class];
     st.macs_alg_dominant = (uint64_t)(cls_alg[st.dominant_class] + 0.5);
