@@ -392,11 +392,6 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             bool owner; // generates the stage-0 items of its W
         };
         const bool allow_flip = !(opt && opt->keep_order == 1);
-        auto flipped = [&](const b2x_pair &p) {
-            const double cur_c = (double)p.k1 * p.k0 * p.n0 + (double)p.m1 * p.k1 * p.n0;
-            const double alt_c = (double)p.m1 * p.k1 * p.k0 + (double)p.m1 * p.k0 * p.n0;
-            return allow_flip && alt_c < 0.95 * cur_c;
-        };
         std::vector<PW> cur;
         uint64_t used = 0;
         auto flush = [&]() {
@@ -603,22 +598,58 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             bool flip;
             uint64_t key[7]; // identifies the stage-0 product
         };
+        auto make_key = [&](const b2x_pair &p, bool fl, uint64_t *key) {
+            if (fl) // W' = op(Z) X: left operator block + psi slice
+                key[0] = 1, key[1] = p.x_off, key[2] = p.z_off, key[3] = ((uint64_t)p.m1 << 32) | (uint32_t)p.k1,
+                key[4] = ((uint64_t)p.k0 << 32) | (uint32_t)p.lda0, key[5] = ((uint64_t)p.lda1 << 8) | p.ta1, key[6] = 0;
+            else // W = X op(Y): psi slice + right operator block
+                key[0] = 0, key[1] = p.x_off, key[2] = p.y_off, key[3] = ((uint64_t)p.k1 << 32) | (uint32_t)p.k0,
+                key[4] = ((uint64_t)p.n0 << 32) | (uint32_t)p.lda0, key[5] = ((uint64_t)p.ldb0 << 8) | p.tb0, key[6] = 0;
+        };
         std::vector<Cand> cand;
         for (const Component *c : big)
             for (uint32_t wi = c->w_begin; wi < c->w_end; wi++) {
-                const b2x_pair &p = pairs[win[wi].pair];
                 Cand cd{};
-                cd.c = c, cd.wi = wi, cd.flip = flipped(p);
-                if (cd.flip) // W' = op(Z) X: left operator block + psi slice
-                    cd.key[0] = 1, cd.key[1] = p.x_off, cd.key[2] = p.z_off,
-                    cd.key[3] = ((uint64_t)p.m1 << 32) | (uint32_t)p.k1, cd.key[4] = ((uint64_t)p.k0 << 32) | (uint32_t)p.lda0,
-                    cd.key[5] = ((uint64_t)p.lda1 << 8) | p.ta1, cd.key[6] = 0;
-                else // W = X op(Y): psi slice + right operator block
-                    cd.key[0] = 0, cd.key[1] = p.x_off, cd.key[2] = p.y_off,
-                    cd.key[3] = ((uint64_t)p.k1 << 32) | (uint32_t)p.k0, cd.key[4] = ((uint64_t)p.n0 << 32) | (uint32_t)p.lda0,
-                    cd.key[5] = ((uint64_t)p.ldb0 << 8) | p.tb0, cd.key[6] = 0;
+                cd.c = c, cd.wi = wi, cd.flip = false;
                 cand.push_back(cd);
             }
+        if (allow_flip) {
+            // order of each pair: stage-0 cost amortised over the pairs that would share the product + its own stage 1
+            struct KeyRef {
+                uint64_t key[7];
+                uint32_t idx;
+            };
+            auto group_sizes = [&](bool fl) {
+                std::vector<KeyRef> ks(cand.size());
+                for (size_t q = 0; q < cand.size(); q++)
+                    make_key(pairs[win[cand[q].wi].pair], fl, ks[q].key), ks[q].idx = (uint32_t)q;
+                std::sort(ks.begin(), ks.end(), [](const KeyRef &x, const KeyRef &y) {
+                    for (int k = 0; k < 7; k++)
+                        if (x.key[k] != y.key[k])
+                            return x.key[k] < y.key[k];
+                    return false;
+                });
+                std::vector<uint32_t> sz(cand.size(), 1);
+                for (size_t a = 0; a < ks.size();) {
+                    size_t b = a + 1;
+                    while (b < ks.size() && std::equal(ks[a].key, ks[a].key + 7, ks[b].key))
+                        b++;
+                    for (size_t q = a; q < b; q++)
+                        sz[ks[q].idx] = (uint32_t)(b - a);
+                    a = b;
+                }
+                return sz;
+            };
+            const std::vector<uint32_t> g0 = group_sizes(false), g1 = group_sizes(true);
+            for (size_t q = 0; q < cand.size(); q++) {
+                const b2x_pair &p = pairs[win[cand[q].wi].pair];
+                const double cur_c = (double)p.k1 * p.k0 * p.n0 / g0[q] + (double)p.m1 * p.k1 * p.n0;
+                const double alt_c = (double)p.m1 * p.k1 * p.k0 / g1[q] + (double)p.m1 * p.k0 * p.n0;
+                cand[q].flip = alt_c < 0.95 * cur_c;
+            }
+        }
+        for (Cand &cd : cand)
+            make_key(pairs[win[cd.wi].pair], cd.flip, cd.key);
         auto key_less = [](const Cand &x, const Cand &y) {
             for (int k = 0; k < 7; k++)
                 if (x.key[k] != y.key[k])
