@@ -58,6 +58,54 @@ def random_rotate_plan(rng, n_sectors=4, max_dim=100, max_terms=12, slices=True)
     return pf
 
 
+def operator_product_plan(rng, n_row=3, n_col=3, max_dim=60, n_left=4, n_right=4, n_terms=10):
+    """Plan of H = sum_t  L_{a(t)} (x) R_{b(t)}  on a psi with n_row x n_col sectors: every operator has a dense block for
+    every (sector, sector) it connects, a term contributes one pair per (row block of L) x (column block of R).  Terms
+    that reuse a right operator share the stage-0 product X.op(Y) of their pairs, terms that reuse a left operator share
+    op(Z).X — the structure the plan compiler exploits.  Returns a PlanFile without data."""
+    rd = [int(rng.integers(1, max_dim + 1)) for _ in range(n_row)]
+    cd = [int(rng.integers(1, max_dim + 1)) for _ in range(n_col)]
+    off = np.zeros((n_row, n_col), np.int64)
+    tot = 0
+    for r in range(n_row):
+        for c in range(n_col):
+            off[r, c], tot = tot, tot + rd[r] * cd[c]
+    arena_len = 0
+
+    def make_op(dims):
+        nonlocal arena_len
+        blocks = {}
+        for i in range(len(dims)):
+            for j in range(len(dims)):
+                if rng.random() < 0.6:
+                    tr = int(rng.integers(0, 2))
+                    blocks[(i, j)] = (arena_len, tr)  # op block maps sector j -> sector i: op(.) is dims[i] x dims[j]
+                    arena_len += dims[i] * dims[j]
+        return blocks
+
+    lops = [make_op(rd) for _ in range(n_left)]
+    rops = [make_op(cd) for _ in range(n_right)]
+    pairs = []
+    for _ in range(n_terms):
+        a, b = int(rng.integers(n_left)), int(rng.integers(n_right))
+        alpha = float(rng.uniform(-1, 1))
+        for (r, rp), (z_off, ta1) in lops[a].items():
+            for (c, cp), (y_off, tb) in rops[b].items():
+                # V(r, c) += alpha * op(Z)(r <- rp) . X(rp, cp) . op(Y)^T(cp -> c);  op(Y) as stored is cd[c] x cd[cp]:
+                # stage 0 needs the (cd[cp] x cd[c]) matrix: tb0 = 1 reads the stored block transposed
+                tb0 = 1 - tb  # stored (c x cp) row-major read transposed, or stored (cp x c) read plain
+                ldb0 = cd[cp] if tb0 else cd[c]
+                lda1 = rd[r] if ta1 else rd[rp]
+                pairs.append(_pair(rd[rp], cd[c], cd[cp], cd[cp], ldb0, rd[r], lda1, cd[c], tb0, ta1, 1.0, alpha,
+                                   off[rp, cp], y_off, z_off, off[r, c]))
+    pf = PlanFile()
+    pf.pairs = np.array(pairs, PAIR_DTYPE)
+    pf.psi_len = pf.sigma_len = int(tot)
+    pf.arena_len = int(arena_len)
+    pf.max_work = int((pf.pairs["m0"].astype(np.int64) * pf.pairs["n0"]).max()) if len(pairs) else 0
+    return pf
+
+
 def _column_offsets(off, m, n, ld):
     """Column index (inside its sector row) of the first element of each window: windows whose address
     ranges overlap belong to one sector; the sector's rows start where a window with col 0 starts."""

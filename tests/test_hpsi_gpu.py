@@ -222,3 +222,20 @@ def test_full_size_m4000_properties(gpu):
     torch.cuda.synchronize()
     assert float((out - hx).abs().max()) <= 1e-10 * float(hx.abs().max())
     generic.close(), arena.close()
+
+
+@pytest.mark.parametrize("seed,scratch_mb,keep_order", [(0, 0, 0), (1, 0, 1), (2, 1, 0), (3, 1, 0), (4, 2, 0)])
+def test_shared_products_and_association(gpu, seed, scratch_mb, keep_order):
+    """operator-product plans (shared stage-0 products, both associations, sharing groups split over super-steps) vs the
+    pair-by-pair oracle; repeatable bit for bit"""
+    rng = np.random.default_rng(500 + seed)
+    pf = fill_plan(synth.operator_product_plan(rng, n_row=3, n_col=4, max_dim=[60, 150, 300, 260, 420][seed], n_left=4,
+                                               n_right=3, n_terms=9), seed)
+    ref = np.zeros(pf.sigma_len)
+    oracle.replay(pf.pairs, pf.arena, pf.psi, ref, 1.0, 8)
+    sig, st = _run(gpu, pf, scratch_mb=scratch_mb, keep_order=keep_order)
+    assert _close(sig, ref), st
+    if not keep_order and st["macs_issued"]:
+        assert st["macs_executed"] < st["macs"]
+    again, _ = _run(gpu, pf, scratch_mb=scratch_mb, keep_order=keep_order)
+    assert np.array_equal(again, sig)

@@ -83,3 +83,20 @@ def test_compiled_two_stage_multi_superstep(built, scratch_mb, item_macs):
     rng = np.random.default_rng(17)
     pf = fill_plan(synth.random_rotate_plan(rng, n_sectors=3, max_dim=400, max_terms=4), 17)
     _check(pf, two_stage=1, scratch_mb=scratch_mb, item_macs=item_macs)
+
+
+@pytest.mark.parametrize("seed,scratch_mb,keep_order", [(0, 0, 0), (1, 0, 1), (2, 1, 0), (3, 1, 0), (4, 0, 0)])
+def test_shared_products_and_association(built, seed, scratch_mb, keep_order):
+    """H = sum of (left operator) x (right operator) products: pairs share stage-0 products and take either association;
+    with a 1 MiB scratch the sharing groups are split over super-steps.  Same sigma as the pair-by-pair oracle, and
+    strictly fewer MACs executed than the reference's order needs."""
+    rng = np.random.default_rng(400 + seed)
+    pf = fill_plan(synth.operator_product_plan(rng, n_row=3, n_col=4, max_dim=[40, 90, 200, 160, 30][seed], n_left=4,
+                                               n_right=3, n_terms=9), seed)
+    st = _check(pf, two_stage=1, scratch_mb=scratch_mb, keep_order=keep_order)
+    if keep_order:
+        assert st["macs_executed"] == st["macs"]
+    else:
+        assert st["macs_executed"] < st["macs"]
+    st2 = _check(pf, scratch_mb=scratch_mb, keep_order=keep_order)  # auto routing
+    assert st2["macs"] == st["macs"]
