@@ -51,6 +51,8 @@ struct b2x_plan {
     GItem *d_gitems = nullptr;
     DTile *d_gtiles = nullptr;
     double *d_scratch = nullptr, *d_gslabs = nullptr;
+    OWork *d_sum_work = nullptr;   // sum pass between the stages (distributive law), scratch -> scratch
+    OEntry *d_sum_entries = nullptr;
     std::vector<SuperStep> steps;
     double *d_psi = nullptr, *d_sigma = nullptr; // staging for host-pointer execute
     size_t psi_len = 0, sigma_len = 0;
@@ -79,6 +81,10 @@ static void plan_free(b2x_plan *p) {
         (void)hipFree(p->d_gtiles);
     if (p->d_scratch)
         (void)hipFree(p->d_scratch);
+    if (p->d_sum_work)
+        (void)hipFree(p->d_sum_work);
+    if (p->d_sum_entries)
+        (void)hipFree(p->d_sum_entries);
     if (p->d_gslabs)
         (void)hipFree(p->d_gslabs);
     if (p->d_psi)
@@ -128,6 +134,10 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
             rc = upload(&p->d_gitems, cp.gitems);
         if (rc == B2X_OK)
             rc = upload(&p->d_gtiles, cp.gtiles);
+        if (rc == B2X_OK)
+            rc = upload(&p->d_sum_work, cp.sum_work);
+        if (rc == B2X_OK)
+            rc = upload(&p->d_sum_entries, cp.sum_entries);
         p->steps = cp.steps;
         if (rc == B2X_OK && cp.scratch_elems) {
             hipError_t e = hipMalloc((void **)&p->d_scratch, (cp.scratch_elems + 8) * sizeof(double));
@@ -327,6 +337,9 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
     HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma, scale, st));
     for (const SuperStep &ss : p->steps) {
         HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, st));
+        if (ss.sum_end > ss.sum_begin)
+            HIPCHK(launch_outer(p->d_sum_work + ss.sum_begin, ss.sum_end - ss.sum_begin, p->d_sum_entries, p->arena->dev,
+                                p->d_scratch, p->d_scratch, st));
         HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, st));
         HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st));
     }
@@ -386,6 +399,9 @@ int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, 
             for (const SuperStep &ss : p->steps) {
                 HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi_dev, p->d_scratch,
                                  p->d_gslabs, p->seg_scaled, st));
+                if (ss.sum_end > ss.sum_begin)
+                    HIPCHK(launch_outer(p->d_sum_work + ss.sum_begin, ss.sum_end - ss.sum_begin, p->d_sum_entries,
+                                        p->arena->dev, p->d_scratch, p->d_scratch, st));
                 HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi_dev, p->d_scratch,
                                  p->d_gslabs, p->seg_scaled, st));
             }

@@ -636,10 +636,14 @@ __global__ __launch_bounds__(256) void outer_build_k(const OWork *__restrict__ w
                     sum[u] += T.alpha * (T.a_src == 2 ? 1.0 : a[u]) * (T.b_src == 2 ? 1.0 : b[u]);
             }
             if (live) {
+                const bool assign = W.ld < 0; // sum pass of the two-stage path: S = ..., not S += ...
+                const uint64_t ld = (uint64_t)(assign ? -W.ld : W.ld);
 #pragma unroll
                 for (int u = 0; u < 4; u++)
-                    if (r + u < r1)
-                        out[W.out_off + (uint64_t)(r + u) * W.ld + c] += sum[u];
+                    if (r + u < r1) {
+                        double *o = out + W.out_off + (uint64_t)(r + u) * ld + c;
+                        *o = assign ? sum[u] : *o + sum[u];
+                    }
             }
         }
     }

@@ -398,6 +398,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             if (cur.empty())
                 return;
             SuperStep ss{};
+            ss.sum_begin = (uint32_t)out.sum_work.size();
+            uint64_t sum_extra = 0; // scratch taken by the sums of this step, behind its W slots
             const uint32_t s0_begin = (uint32_t)out.gitems.size();
             // stage 0: tiles of every W
             for (const PW &pw : cur) {
@@ -483,7 +485,76 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 int nrt = (int)rc.size() - 1, nct = (int)cc.size() - 1;
                 std::vector<std::vector<GSeg>> tsegs((size_t)nrt * nct);
                 std::vector<double> tcost((size_t)nrt * nct, 0.0);
+                // Distributive law: pairs of this sector that multiply the SAME operator block into the SAME window
+                // (op(Z) . W_i with one Z, or W'_i . op(Y) with one Y) first sum their scaled stage-0 products,
+                // S = sum_i alpha_i W_i, in an element-wise pass between the stages, then take ONE stage-1 product.
+                // Worth it only where the saved MACs outweigh the pass at HBM speed: (g - 1)/(g + 1) x (rows of Z, or
+                // columns of op(Y)) > 64 MAC per element moved.
+                std::vector<uint64_t> merged_off(j - i, ~(uint64_t)0); // S offset of a group's first member
+                std::vector<uint8_t> merged_skip(j - i, 0);             // later members: no segment of their own
+                if (allow_flip && j - i > 1 && !getenv("B2X_NO_MERGE")) {
+                    struct MK {
+                        uint64_t k[6];
+                        uint32_t q;
+                    };
+                    std::vector<MK> mk(j - i);
+                    for (size_t q = i; q < j; q++) {
+                        const Window &w = win[cur[q].wi];
+                        const b2x_pair &p = pairs[w.pair];
+                        MK &m = mk[q - i];
+                        m.q = (uint32_t)q;
+                        m.k[0] = cur[q].flip, m.k[1] = cur[q].flip ? p.y_off : p.z_off, m.k[2] = w.off;
+                        m.k[3] = ((uint64_t)p.m1 << 32) | (uint32_t)p.n0, m.k[4] = cur[q].flip ? (uint64_t)p.k0 : (uint64_t)p.k1;
+                        m.k[5] = cur[q].flip ? (((uint64_t)p.ldb0 << 8) | p.tb0) : (((uint64_t)p.lda1 << 8) | p.ta1);
+                    }
+                    std::stable_sort(mk.begin(), mk.end(), [](const MK &x, const MK &y) {
+                        for (int k = 0; k < 6; k++)
+                            if (x.k[k] != y.k[k])
+                                return x.k[k] < y.k[k];
+                        return false;
+                    });
+                    for (size_t a = 0; a < mk.size();) {
+                        size_t b = a + 1;
+                        while (b < mk.size() && std::equal(mk[a].k, mk[a].k + 6, mk[b].k))
+                            b++;
+                        const size_t gsz = b - a;
+                        const b2x_pair &p0 = pairs[win[cur[mk[a].q].wi].pair];
+                        const bool fl = cur[mk[a].q].flip;
+                        const double dim = fl ? (double)p0.n0 : (double)p0.m1;
+                        if (gsz > 1 && dim * (double)(gsz - 1) / (double)(gsz + 1) > 64.0) {
+                            const int srows = fl ? p0.m1 : p0.k1, scols = fl ? p0.k0 : p0.n0;
+                            const uint64_t s_off = used + sum_extra;
+                            sum_extra += (((uint64_t)srows * scols) + 1) & ~(uint64_t)1;
+                            const uint32_t eb = (uint32_t)out.sum_entries.size();
+                            for (size_t x = a; x < b; x++) {
+                                const b2x_pair &px = pairs[win[cur[mk[x].q].wi].pair];
+                                OEntry e{};
+                                e.a_off = cur[mk[x].q].w_off, e.b_off = 0, e.alpha = px.alpha0 * px.alpha1;
+                                e.a_rs = scols, e.a_cs = 1, e.b_rs = e.b_cs = 0, e.a_src = 1, e.b_src = 2;
+                                out.sum_entries.push_back(e);
+                                if (x > a)
+                                    merged_skip[mk[x].q - i] = 1;
+                            }
+                            merged_off[mk[a].q - i] = s_off;
+                            OWork wk{};
+                            wk.out_off = s_off, wk.ld = -scols, wk.rows = srows, wk.cols = scols; // ld < 0: assign
+                            wk.rpt = std::max(4, std::min(64, 256 / (int)std::min<size_t>(gsz, 64)));
+                            wk.entry_begin = eb, wk.entry_end = (uint32_t)out.sum_entries.size();
+                            const uint32_t nseg = (uint32_t)ceil_div(scols, kOuterTileCols), nstrip = (uint32_t)ceil_div(srows, wk.rpt);
+                            const uint32_t ntile = nseg * nstrip, per = ntile >= 4096 ? 4 : (ntile >= 1024 ? 2 : 1);
+                            for (uint32_t t0 = 0; t0 < ntile; t0 += per) {
+                                wk.t_begin = t0, wk.t_end = std::min(ntile, t0 + per);
+                                out.sum_work.push_back(wk);
+                            }
+                        }
+                        a = b;
+                    }
+                }
                 for (size_t q = i; q < j; q++) {
+                    if (merged_skip[q - i])
+                        continue;
+                    const bool msum = merged_off[q - i] != ~(uint64_t)0; // reads the group's sum, already scaled
+                    const uint64_t src_off = msum ? merged_off[q - i] : cur[q].w_off;
                     const Window &w = win[cur[q].wi];
                     const b2x_pair &p = pairs[w.pair];
                     uint64_t rel = w.off - c.base;
@@ -497,21 +568,21 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             int r_lo = ra - row0, c_lo = ca - col0;
                             GSeg g{};
                             if (cur[q].flip) { // V[window] += W'(m1 x k0) . op(Y)(k0 x n)
-                                g.a_src = 2, g.a_off = cur[q].w_off + (uint64_t)r_lo * p.k0, g.a_sr = p.k0, g.a_sk = 1;
+                                g.a_src = 2, g.a_off = src_off + (uint64_t)r_lo * p.k0, g.a_sr = p.k0, g.a_sk = 1;
                                 g.b_src = 0;
                                 if (p.tb0)
                                     g.b_off = p.y_off + (uint64_t)c_lo * p.ldb0, g.b_sk = 1, g.b_sc = p.ldb0;
                                 else
                                     g.b_off = p.y_off + (uint64_t)c_lo, g.b_sk = p.ldb0, g.b_sc = 1;
-                                g.K = p.k0, g.alpha = p.alpha0 * p.alpha1;
+                                g.K = p.k0, g.alpha = msum ? 1.0 : p.alpha0 * p.alpha1;
                             } else {
                             g.a_src = 0;
                             if (p.ta1)
                                 g.a_off = p.z_off + (uint64_t)r_lo, g.a_sr = 1, g.a_sk = p.lda1;
                             else
                                 g.a_off = p.z_off + (uint64_t)r_lo * p.lda1, g.a_sr = p.lda1, g.a_sk = 1;
-                            g.b_src = 2, g.b_off = cur[q].w_off + (uint64_t)c_lo, g.b_sk = p.n0, g.b_sc = 1;
-                            g.K = p.k1, g.alpha = p.alpha0 * p.alpha1;
+                            g.b_src = 2, g.b_off = src_off + (uint64_t)c_lo, g.b_sk = p.n0, g.b_sc = 1;
+                            g.K = p.k1, g.alpha = msum ? 1.0 : p.alpha0 * p.alpha1;
                             }
                             g.mr = rb - ra, g.nc = cb - ca;
                             g.tc0 = ca - cc[b]; // (ra == rc[a]: rows are cut at every window boundary)
@@ -586,8 +657,9 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
                     st.macs_issued += tm * (uint64_t)round_up(it.cols, 16 * kGGCF) * (uint64_t)round_up(out.gsegs[k].K, 16);
             }
+            ss.sum_end = (uint32_t)out.sum_work.size();
             out.steps.push_back(ss);
-            out.scratch_elems = std::max(out.scratch_elems, used);
+            out.scratch_elems = std::max(out.scratch_elems, used + sum_extra);
             out.gslab_elems = std::max(out.gslab_elems, slab);
             cur.clear();
             used = 0;
@@ -1013,7 +1085,10 @@ void emulate_outer_host(const std::vector<OWork> &work, const std::vector<OEntry
                         const double b = t.b_src == 2 ? one : (t.b_src ? in : arena)[t.b_off + (uint64_t)r * t.b_rs + (uint64_t)c * t.b_cs];
                         sum += t.alpha * a * b;
                     }
-                    out[w.out_off + (uint64_t)r * w.ld + c] += sum;
+                    if (w.ld < 0)
+                        out[w.out_off + (uint64_t)r * (uint64_t)(-w.ld) + c] = sum;
+                    else
+                        out[w.out_off + (uint64_t)r * w.ld + c] += sum;
                 }
         }
     }
@@ -1149,6 +1224,11 @@ void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double
     for (const SuperStep &ss : cp.steps) {
         for (uint32_t i = ss.s0_v[0]; i < ss.s0_v[kGGVariants]; i++)
             run_item(cp.gitems[i]);
+        if (ss.sum_end > ss.sum_begin) { // S = sum_i alpha_i W_i (scratch -> scratch)
+            std::vector<OWork> wk(cp.sum_work.begin() + ss.sum_begin, cp.sum_work.begin() + ss.sum_end);
+            std::vector<double> src = scratch;
+            emulate_outer_host(wk, cp.sum_entries, arena, src.data(), scratch.data());
+        }
         for (uint32_t i = ss.s1_v[0]; i < ss.s1_v[kGGVariants]; i++)
             run_item(cp.gitems[i]);
         for (uint32_t ti = ss.tile_begin; ti < ss.tile_end; ti++) {

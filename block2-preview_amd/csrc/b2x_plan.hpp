@@ -70,6 +70,28 @@ struct GItem {
 };
 static_assert(sizeof(GItem) == 40, "GItem layout");
 
+// ---- element-wise block products (blocking) ---------------------------------------------------------------------
+// The windows of one output sector are cut along all their row / column boundaries into CELLS; a cell lists the terms
+// that cover it with operand offsets already moved to the cell origin, so the kernel walks a cell's list without any
+// window test.  A cell is covered by TILES of 64 columns x rpt rows (tile id = strip * n_col_segments + segment); a
+// work unit is a range of tiles of one cell and is executed by ONE WAVE (four units per workgroup).
+struct OEntry {
+    uint64_t a_off, b_off;
+    double alpha;
+    int32_t a_rs, a_cs, b_rs, b_cs;
+    int32_t a_src, b_src;
+};
+static_assert(sizeof(OEntry) == 48, "OEntry layout");
+struct OWork {
+    uint64_t out_off; // output offset of the cell's (0, 0)
+    int32_t ld, rows, cols;
+    int32_t rpt;                   // rows per tile
+    uint32_t t_begin, t_end;       // tile range of the cell handled by this unit
+    uint32_t entry_begin, entry_end;
+};
+static_assert(sizeof(OWork) == 40, "OWork layout");
+static const int kOuterTileCols = 64;
+
 // stage 0 of a batch of pairs -> W scratch; stage 1 consumes it; reduce adds the slabs into psi'.
 // All items of a stage share one launch (range [s?_v[0], s?_v[kGGVariants])); every workgroup picks the kernel body
 // for its tile height (rows rounded up to 16).
@@ -78,6 +100,7 @@ struct SuperStep {
     uint32_t s0_v[kGGVariants + 1];
     uint32_t s1_v[kGGVariants + 1];
     uint32_t tile_begin, tile_end; // DTile range (two-stage tile list)
+    uint32_t sum_begin, sum_end;   // OWork range of the sum pass between the stages (CompiledPlan::sum_work)
 };
 
 // tile of one workgroup of the grouped-GEMM kernel: kGGTileN / (16 * kGGCF) waves, each kGGCF column fragments wide
@@ -116,6 +139,10 @@ struct CompiledPlan {
     bool fallback = false; // windows could not be segmented -> generic atomic kernel
     std::string fallback_reason;
     bool seg_scaled = false; // single-GEMM list: segments carry their own alpha (gg_kernel SCALED variant)
+    // sum pass of the two-stage path: S = sum_i alpha_i W_i for pairs that multiply the same operator block into the same
+    // psi' window (scratch -> scratch, element-wise; OWork::ld < 0 marks "assign" instead of "accumulate")
+    std::vector<OWork> sum_work;
+    std::vector<OEntry> sum_entries;
 };
 
 // ---- diagonal build ----------------------------------------------------------------------------------------
@@ -130,27 +157,6 @@ struct DiagComp {
     int32_t ld, rows, cols;
     uint32_t term_begin, term_end;
 };
-// ---- element-wise block products (blocking) ---------------------------------------------------------------------
-// The windows of one output sector are cut along all their row / column boundaries into CELLS; a cell lists the terms
-// that cover it with operand offsets already moved to the cell origin, so the kernel walks a cell's list without any
-// window test.  A cell is covered by TILES of 64 columns x rpt rows (tile id = strip * n_col_segments + segment); a
-// work unit is a range of tiles of one cell and is executed by ONE WAVE (four units per workgroup).
-struct OEntry {
-    uint64_t a_off, b_off;
-    double alpha;
-    int32_t a_rs, a_cs, b_rs, b_cs;
-    int32_t a_src, b_src;
-};
-static_assert(sizeof(OEntry) == 48, "OEntry layout");
-struct OWork {
-    uint64_t out_off; // output offset of the cell's (0, 0)
-    int32_t ld, rows, cols;
-    int32_t rpt;                   // rows per tile
-    uint32_t t_begin, t_end;       // tile range of the cell handled by this unit
-    uint32_t entry_begin, entry_end;
-};
-static_assert(sizeof(OWork) == 40, "OWork layout");
-static const int kOuterTileCols = 64;
 int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, size_t out_len, uint64_t arena_len,
                   std::vector<OWork> &work, std::vector<OEntry> &entries, std::string &err);
 // host evaluation of the compiled work list (TEST HOOK)
