@@ -220,10 +220,10 @@ class GemmPlan(Plan):
     """Device-resident single-GEMM list (batch[1] of BatchGEMMSeq after a partial multiply, before auto_perform(v)):
     out += scale * sum_i alpha_i op(A_i) op(B_i), operands from the arena or the input vector."""
 
-    def __init__(self, arena, gemms, in_len, out_len, item_macs=0):
+    def __init__(self, arena, gemms, in_len, out_len, item_macs=0, keep_order=0):
         gemms = np.ascontiguousarray(gemms, GEMM_DTYPE)
         opt = PlanOptions()
-        opt.item_macs = item_macs
+        opt.item_macs, opt.keep_order = item_macs, keep_order
         h = C.c_void_p()
         check(lib().b2x_gemm_plan_create(C.byref(h), arena._h, C.c_size_t(len(gemms)), _ptr(gemms), C.c_size_t(in_len),
                                          C.c_size_t(out_len), C.byref(opt)))
@@ -252,11 +252,11 @@ def debug_compile_and_emulate_outer(terms, arena, vin, vout):
     return nw.value, ne.value
 
 
-def debug_compile_and_emulate_gemms(gemms, in_len, out_len, arena, vin, vout, scale=1.0, item_macs=0):
+def debug_compile_and_emulate_gemms(gemms, in_len, out_len, arena, vin, vout, scale=1.0, item_macs=0, keep_order=0):
     """TEST HOOK: compile a single-GEMM list and evaluate the compiled work list with host loops."""
     gemms = np.ascontiguousarray(gemms, GEMM_DTYPE)
     opt = PlanOptions()
-    opt.item_macs = item_macs
+    opt.item_macs, opt.keep_order = item_macs, keep_order
     st = PlanStats()
     check(lib().b2x_debug_compile_and_emulate_gemms(
         C.c_size_t(len(gemms)), _ptr(gemms), C.c_size_t(in_len), C.c_size_t(out_len), C.c_uint64(arena.size),

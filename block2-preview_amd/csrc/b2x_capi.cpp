@@ -339,7 +339,7 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
         HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, st));
         if (ss.sum_end > ss.sum_begin)
             HIPCHK(launch_outer(p->d_sum_work + ss.sum_begin, ss.sum_end - ss.sum_begin, p->d_sum_entries, p->arena->dev,
-                                p->d_scratch, p->d_scratch, st));
+                                p->d_scratch, p->d_scratch, 16, st));
         HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, st));
         HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st));
     }
@@ -401,7 +401,7 @@ int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, 
                                  p->d_gslabs, p->seg_scaled, st));
                 if (ss.sum_end > ss.sum_begin)
                     HIPCHK(launch_outer(p->d_sum_work + ss.sum_begin, ss.sum_end - ss.sum_begin, p->d_sum_entries,
-                                        p->arena->dev, p->d_scratch, p->d_scratch, st));
+                                        p->arena->dev, p->d_scratch, p->d_scratch, 16, st));
                 HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi_dev, p->d_scratch,
                                  p->d_gslabs, p->seg_scaled, st));
             }
@@ -527,7 +527,7 @@ int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term
             rc = fail(B2X_ERR_DEVICE, std::string("b2x_outer_build: ") + hipGetErrorString(e));
     }
     if (rc == B2X_OK) {
-        hipError_t e = launch_outer(dw, (uint32_t)work.size(), de, arena->dev, d_in, d_out, st);
+        hipError_t e = launch_outer(dw, (uint32_t)work.size(), de, arena->dev, d_in, d_out, 4, st);
         if (e == hipSuccess)
             e = hipStreamSynchronize(st); // metadata is freed below
         if (e == hipSuccess && !on_device)

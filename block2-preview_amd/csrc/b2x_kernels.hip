@@ -603,6 +603,8 @@ hipError_t launch_diag(const DiagComp *comps, uint32_t n_comps, const DiagTermD 
 // dispatch).  Lane = column, the wave walks the tile's rows four at a time (4 x entries loads in flight) and the
 // entry list in plan order with no window test: deterministic, no atomics.  HBM-bound: non-transposed blocks are read
 // as 512-byte row segments; a transposed block is read with one cache line per lane that the next rows reuse from L1/L2.
+template <int RU> // rows in flight per entry visit: 4 (blocking: short tiles), 16 (operator sums: a transposed block is read one
+                   // cache line per lane, and 16 rows consume every element of the line before the next entry evicts it)
 __global__ __launch_bounds__(256) void outer_build_k(const OWork *__restrict__ work, uint32_t n_work,
                                                       const OEntry *__restrict__ entries, const double *__restrict__ arena,
                                                       const double *__restrict__ in, double *__restrict__ out) {
@@ -617,29 +619,29 @@ __global__ __launch_bounds__(256) void outer_build_k(const OWork *__restrict__ w
         const int r1 = min(W.rows, r0 + W.rpt);
         const bool live = c < W.cols;
         const uint64_t cc = (uint64_t)min(c, W.cols - 1); // clamped: dead lanes load a valid element and drop it
-        for (int r = r0; r < r1; r += 4) {
-            double sum[4] = {0.0, 0.0, 0.0, 0.0};
-            uint64_t rr[4];
+        for (int r = r0; r < r1; r += RU) {
+            double sum[RU];
+            uint64_t rr[RU];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                rr[u] = (uint64_t)min(r + u, r1 - 1);
+            for (int u = 0; u < RU; u++)
+                sum[u] = 0.0, rr[u] = (uint64_t)min(r + u, r1 - 1);
             for (uint32_t k = W.entry_begin; k < W.entry_end; k++) {
                 const OEntry T = entries[k];
                 const double *pa = (T.a_src == 1 ? in : arena) + T.a_off + cc * (uint64_t)T.a_cs;
                 const double *pb = (T.b_src == 1 ? in : arena) + T.b_off + cc * (uint64_t)T.b_cs;
-                double a[4], b[4];
+                double a[RU], b[RU];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < RU; u++)
                     a[u] = pa[rr[u] * (uint64_t)T.a_rs], b[u] = pb[rr[u] * (uint64_t)T.b_rs];
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < RU; u++)
                     sum[u] += T.alpha * (T.a_src == 2 ? 1.0 : a[u]) * (T.b_src == 2 ? 1.0 : b[u]);
             }
             if (live) {
                 const bool assign = W.ld < 0; // sum pass of the two-stage path: S = ..., not S += ...
                 const uint64_t ld = (uint64_t)(assign ? -W.ld : W.ld);
 #pragma unroll
-                for (int u = 0; u < 4; u++)
+                for (int u = 0; u < RU; u++)
                     if (r + u < r1) {
                         double *o = out + W.out_off + (uint64_t)(r + u) * ld + c;
                         *o = assign ? sum[u] : *o + sum[u];
@@ -649,10 +651,13 @@ __global__ __launch_bounds__(256) void outer_build_k(const OWork *__restrict__ w
     }
 }
 hipError_t launch_outer(const OWork *work, uint32_t n_work, const OEntry *entries, const double *arena, const double *in,
-                        double *out, hipStream_t st) {
+                        double *out, int rows_in_flight, hipStream_t st) {
     if (n_work == 0)
         return hipSuccess;
-    hipLaunchKernelGGL(outer_build_k, dim3((n_work + 3) / 4), dim3(256), 0, st, work, n_work, entries, arena, in, out);
+    if (rows_in_flight >= 16)
+        hipLaunchKernelGGL(outer_build_k<16>, dim3((n_work + 3) / 4), dim3(256), 0, st, work, n_work, entries, arena, in, out);
+    else
+        hipLaunchKernelGGL(outer_build_k<4>, dim3((n_work + 3) / 4), dim3(256), 0, st, work, n_work, entries, arena, in, out);
     return hipGetLastError();
 }
 

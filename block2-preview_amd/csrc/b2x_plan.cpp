@@ -538,7 +538,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             merged_off[mk[a].q - i] = s_off;
                             OWork wk{};
                             wk.out_off = s_off, wk.ld = -scols, wk.rows = srows, wk.cols = scols; // ld < 0: assign
-                            wk.rpt = std::max(4, std::min(64, 256 / (int)std::min<size_t>(gsz, 64)));
+                            wk.rpt = 16; // outer_build_k<16>
                             wk.entry_begin = eb, wk.entry_end = (uint32_t)out.sum_entries.size();
                             const uint32_t nseg = (uint32_t)ceil_div(scols, kOuterTileCols), nstrip = (uint32_t)ceil_div(srows, wk.rpt);
                             const uint32_t ntile = nseg * nstrip, per = ntile >= 4096 ? 4 : (ntile >= 1024 ? 2 : 1);
@@ -823,9 +823,104 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     }
     if (n_gemms == 0)
         return B2X_OK;
-    std::vector<Window> win(n_gemms);
-    for (size_t i = 0; i < n_gemms; i++)
-        win[i] = Window{gemms[i].c_off, gemms[i].m, gemms[i].n, gemms[i].ldc, (uint32_t)i};
+    // ---- distributive law ------------------------------------------------------------------------------------------
+    // Records that multiply the SAME block of the input vector into the SAME output window,
+    //     C += sum_i alpha_i op(A_i) . X      or      C += X . sum_i alpha_i op(B_i),
+    // (the reduced perturbative noise applies every left / right operator of the Hamiltonian to the same psi blocks:
+    // on the Cr2 M=250 list 155 728 records fall into 1 400 such groups) first sum their operator blocks,
+    // S = sum_i alpha_i op(A_i), in an element-wise pass (outer_build_k into the scratch, strides take care of mixed
+    // transposes), then take ONE product.  Worth it where the product saved per member outweighs reading its operator
+    // block once more: (g - 1)/(g + 1) x (columns of X, or rows of X) > 8.  keep_order = 1 replays record by record.
+    std::vector<b2x_gemm> eff_store;
+    const b2x_gemm *eff = gemms;
+    size_t n_eff = n_gemms;
+    if (!(opt && opt->keep_order == 1)) {
+        struct MK {
+            uint64_t k[7];
+            uint32_t i;
+        };
+        std::vector<MK> mk;
+        std::vector<uint8_t> taken(n_gemms, 0);
+        for (size_t i = 0; i < n_gemms; i++) {
+            const b2x_gemm &g = gemms[i];
+            const bool right = g.a_src == 0 && g.b_src == 1, left = g.a_src == 1 && g.b_src == 0;
+            if (!right && !left)
+                continue;
+            MK m{};
+            m.i = (uint32_t)i;
+            m.k[0] = right, m.k[1] = right ? g.b_off : g.a_off, m.k[2] = g.c_off;
+            m.k[3] = ((uint64_t)g.m << 32) | (uint32_t)g.n, m.k[4] = ((uint64_t)g.k << 32) | (uint32_t)g.ldc;
+            m.k[5] = right ? (((uint64_t)g.ldb << 8) | g.tb) : (((uint64_t)g.lda << 8) | g.ta), m.k[6] = 0;
+            mk.push_back(m);
+        }
+        std::stable_sort(mk.begin(), mk.end(), [](const MK &x, const MK &y) {
+            for (int k = 0; k < 7; k++)
+                if (x.k[k] != y.k[k])
+                    return x.k[k] < y.k[k];
+            return false;
+        });
+        uint64_t s_used = 0;
+        std::vector<b2x_gemm> merged;
+        for (size_t a = 0; a < mk.size();) {
+            size_t b = a + 1;
+            while (b < mk.size() && std::equal(mk[a].k, mk[a].k + 7, mk[b].k))
+                b++;
+            const size_t gsz = b - a;
+            const b2x_gemm &g0 = gemms[mk[a].i];
+            const bool right = g0.a_src == 0;
+            const double dim = right ? (double)g0.n : (double)g0.m;
+            if (gsz > 1 && dim * (double)(gsz - 1) / (double)(gsz + 1) > 8.0) {
+                const int srows = right ? g0.m : g0.k, scols = right ? g0.k : g0.n; // S = sum op(A_i) or sum op(B_i)
+                const uint64_t s_off = s_used;
+                s_used += (((uint64_t)srows * scols) + 1) & ~(uint64_t)1;
+                const uint32_t eb = (uint32_t)out.sum_entries.size();
+                for (size_t x = a; x < b; x++) {
+                    const b2x_gemm &gx = gemms[mk[x].i];
+                    OEntry e{};
+                    const bool tr = right ? gx.ta : gx.tb;
+                    const int ld = right ? gx.lda : gx.ldb;
+                    e.a_off = right ? gx.a_off : gx.b_off, e.alpha = gx.alpha;
+                    e.a_rs = tr ? 1 : ld, e.a_cs = tr ? ld : 1, e.a_src = 0, e.b_src = 2;
+                    out.sum_entries.push_back(e);
+                    taken[mk[x].i] = 1;
+                }
+                OWork wk{};
+                wk.out_off = s_off, wk.ld = -scols, wk.rows = srows, wk.cols = scols; // ld < 0: assign
+                // a transposed member is read one cache line per lane; 16 rows per tile use every element of the line
+                bool any_tr = false;
+                for (uint32_t e = eb; e < (uint32_t)out.sum_entries.size(); e++)
+                    any_tr = any_tr || (out.sum_entries[e].a_rs == 1 && out.sum_entries[e].a_cs > 1);
+                (void)any_tr;
+                wk.rpt = 16; // outer_build_k<16>: sixteen rows in flight per entry visit
+                wk.entry_begin = eb, wk.entry_end = (uint32_t)out.sum_entries.size();
+                const uint32_t nseg = (uint32_t)ceil_div(scols, kOuterTileCols), nstrip = (uint32_t)ceil_div(srows, wk.rpt);
+                const uint32_t ntile = nseg * nstrip;
+                for (uint32_t t0 = 0; t0 < ntile; t0++) { // one tile per wave: the entry lists are long
+                    wk.t_begin = t0, wk.t_end = t0 + 1;
+                    out.sum_work.push_back(wk);
+                }
+                b2x_gemm r = g0; // one product with the summed operator (source 2 = scratch, internal)
+                r.alpha = 1.0;
+                if (right)
+                    r.a_src = 2, r.a_off = s_off, r.lda = scols, r.ta = 0;
+                else
+                    r.b_src = 2, r.b_off = s_off, r.ldb = scols, r.tb = 0;
+                merged.push_back(r);
+            }
+            a = b;
+        }
+        if (!merged.empty()) {
+            for (size_t i = 0; i < n_gemms; i++)
+                if (!taken[i])
+                    eff_store.push_back(gemms[i]);
+            eff_store.insert(eff_store.end(), merged.begin(), merged.end());
+            eff = eff_store.data(), n_eff = eff_store.size();
+            out.scratch_elems = s_used;
+        }
+    }
+    std::vector<Window> win(n_eff);
+    for (size_t i = 0; i < n_eff; i++)
+        win[i] = Window{eff[i].c_off, eff[i].m, eff[i].n, eff[i].ldc, (uint32_t)i};
     bool bad = false;
     std::string reason;
     std::vector<Component> comps = build_components(win, bad, reason);
@@ -834,9 +929,12 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
         return B2X_ERR_INVALID;
     }
     st.n_targets = comps.size();
+    double eff_macs = 0;
+    for (size_t i = 0; i < n_eff; i++)
+        eff_macs += (double)eff[i].m * eff[i].n * eff[i].k;
     const int TN = kGGTileN;
     // item size as in compile_plan: ~8 rounds over the workgroup slots, between 2e6 and 6e7 MFMA-slot units
-    const double per_item = opt && opt->item_macs > 0 ? (double)opt->item_macs : std::min(6.0e7, std::max(2.0e6, (double)st.macs / 4096.0));
+    const double per_item = opt && opt->item_macs > 0 ? (double)opt->item_macs : std::min(6.0e7, std::max(2.0e6, eff_macs / 4096.0));
     SuperStep ss{};
     uint64_t slab = 0, gg_macs = 0;
     for (const Component &c : comps) {
@@ -865,7 +963,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
         std::sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) { return win[a].pair < win[b].pair; });
         for (uint32_t wi : members) {
             const Window &w = win[wi];
-            const b2x_gemm &p = gemms[w.pair];
+            const b2x_gemm &p = eff[w.pair];
             uint64_t rel = w.off - c.base;
             int row0 = (int)(rel / (uint64_t)c.ld), col0 = (int)(rel % (uint64_t)c.ld);
             int a0 = (int)(std::upper_bound(rc.begin(), rc.end(), row0) - rc.begin()) - 1;
@@ -938,6 +1036,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
         ss.s0_v[k] = 0, ss.s1_v[k] = 0;
     ss.s1_v[kGGVariants] = (uint32_t)out.gitems.size();
     ss.tile_begin = 0, ss.tile_end = (uint32_t)out.gtiles.size();
+    ss.sum_begin = 0, ss.sum_end = (uint32_t)out.sum_work.size();
     for (const GItem &it : out.gitems) {
         uint64_t tm = (uint64_t)kGGRowUnit * (uint64_t)(variant(it) + 1);
         for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
@@ -947,7 +1046,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     out.gslab_elems = slab;
     st.n_tiles = out.gtiles.size(), st.n_items = out.gitems.size(), st.n_parts = out.gsegs.size();
     st.macs_executed = gg_macs;
-    st.dominant_class = kNumClasses, st.macs_dominant = gg_macs, st.macs_alg_dominant = gg_macs, st.n_launches = 1;
+    st.dominant_class = kNumClasses, st.macs_dominant = gg_macs, st.macs_alg_dominant = st.macs, st.n_launches = 1;
     st.device_bytes = out.gslab_elems * 8 + out.gsegs.size() * sizeof(GSeg) + out.gitems.size() * sizeof(GItem) +
                       out.gtiles.size() * sizeof(DTile);
     return B2X_OK;

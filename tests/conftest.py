@@ -18,7 +18,7 @@ def pytest_configure(config):
     # runtime before libb2x.so pulls in the system one (the other order leaves torch without a device), so when the GPU
     # tests are selected torch is imported here, before any fixture touches libb2x.
     expr = config.getoption("markexpr", "") or ""
-    if "gpu" in expr and "not gpu" not in expr:
+    if ("gpu" in expr and "not gpu" not in expr) or (os.path.exists("/dev/kfd") and "not gpu" not in expr):
         try:
             import torch
 

@@ -112,8 +112,13 @@ def test_compiled_gemm_list_matches_reference(built, fn):
 
     gl = read_gemm_list(fn)
     out = np.zeros(gl.out_len)
+    st = capi.debug_compile_and_emulate_gemms(gl.gemms, gl.in_len, gl.out_len, gl.arena, gl.vin, out, keep_order=1)
+    assert st["macs"] == gl.macs and st["macs_executed"] == gl.macs  # record by record, as the reference replays it
+    assert np.abs(out - gl.out_ref).max() <= 1e-12 * max(1.0, np.abs(gl.out_ref).max())
+    # shipped: operator blocks that meet the same psi block in the same output window are summed first
+    out = np.zeros(gl.out_len)
     st = capi.debug_compile_and_emulate_gemms(gl.gemms, gl.in_len, gl.out_len, gl.arena, gl.vin, out)
-    assert st["macs"] == gl.macs and st["macs_executed"] == gl.macs
+    assert st["macs"] == gl.macs and st["macs_executed"] <= gl.macs
     assert np.abs(out - gl.out_ref).max() <= 1e-12 * max(1.0, np.abs(gl.out_ref).max())
 
 

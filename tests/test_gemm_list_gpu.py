@@ -37,7 +37,10 @@ def test_golden_reference_noise(gpu, fn):
     """perturbed wavefunctions from the MFMA path == what the reference's perturbative_noise returned"""
     gl = read_gemm_list(fn)
     out, st = _run(gpu, gl, gl.arena, gl.vin)
-    assert st["macs"] == gl.macs
+    assert st["macs"] == gl.macs and st["macs_executed"] <= gl.macs
+    assert _close(out, gl.out_ref)
+    out, st = _run(gpu, gl, gl.arena, gl.vin, keep_order=1)  # record by record
+    assert st["macs_executed"] == gl.macs
     assert _close(out, gl.out_ref)
 
 
