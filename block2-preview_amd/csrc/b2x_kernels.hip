@@ -603,7 +603,7 @@ hipError_t launch_diag(const DiagComp *comps, uint32_t n_comps, const DiagTermD 
 // dispatch).  Lane = column, the wave walks the tile's rows four at a time (4 x entries loads in flight) and the
 // entry list in plan order with no window test: deterministic, no atomics.  HBM-bound: non-transposed blocks are read
 // as 512-byte row segments; a transposed block is read with one cache line per lane that the next rows reuse from L1/L2.
-template <int RU> // rows in flight per entry visit: 4 (blocking: short tiles), 16 (operator sums: a transposed block is read one
+template <int RU, bool HASB> // HASB = false: every B operand is the constant 1 (operator sums); RU = rows in flight per entry visit: 4 (blocking: short tiles), 16 (operator sums: a transposed block is read one
                    // cache line per lane, and 16 rows consume every element of the line before the next entry evicts it)
 __global__ __launch_bounds__(256) void outer_build_k(const OWork *__restrict__ work, uint32_t n_work,
                                                       const OEntry *__restrict__ entries, const double *__restrict__ arena,
@@ -625,17 +625,51 @@ __global__ __launch_bounds__(256) void outer_build_k(const OWork *__restrict__ w
 #pragma unroll
             for (int u = 0; u < RU; u++)
                 sum[u] = 0.0, rr[u] = (uint64_t)min(r + u, r1 - 1);
-            for (uint32_t k = W.entry_begin; k < W.entry_end; k++) {
-                const OEntry T = entries[k];
+            const bool full_rows = r + RU <= r1; // no clamped (repeated) row among the RU in flight
+            // software pipeline over the entry list: the loads of entry k + 1 are in flight while entry k is consumed
+            // (descriptor by scalar loads one entry ahead, operands in a second register set)
+            double a_n[RU], b_n[RU];
+            OEntry Tn = entries[W.entry_begin];
+            auto issue = [&](const OEntry &T) __attribute__((always_inline)) {
                 const double *pa = (T.a_src == 1 ? in : arena) + T.a_off + cc * (uint64_t)T.a_cs;
-                const double *pb = (T.b_src == 1 ? in : arena) + T.b_off + cc * (uint64_t)T.b_cs;
+                if (RU >= 4 && T.a_rs == 1 && full_rows) { // transposed block: the lane's rows are contiguous, 32-byte loads
+#pragma unroll
+                    for (int u = 0; u < RU; u += 4) {
+                        const d4u v = *(const d4u *)(pa + rr[u]);
+                        a_n[u] = v[0], a_n[u + 1] = v[1], a_n[u + 2] = v[2], a_n[u + 3] = v[3];
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RU; u++)
+                        a_n[u] = pa[rr[u] * (uint64_t)T.a_rs];
+                }
+                if (HASB) {
+                    if (T.b_src != 2) { // (wave-uniform: the descriptor lives in SGPRs)
+                        const double *pb = (T.b_src == 1 ? in : arena) + T.b_off + cc * (uint64_t)T.b_cs;
+#pragma unroll
+                        for (int u = 0; u < RU; u++)
+                            b_n[u] = pb[rr[u] * (uint64_t)T.b_rs];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < RU; u++)
+                            b_n[u] = 1.0;
+                    }
+                }
+            };
+            issue(Tn);
+            for (uint32_t k = W.entry_begin; k < W.entry_end; k++) {
+                const OEntry T = Tn;
                 double a[RU], b[RU];
 #pragma unroll
                 for (int u = 0; u < RU; u++)
-                    a[u] = pa[rr[u] * (uint64_t)T.a_rs], b[u] = pb[rr[u] * (uint64_t)T.b_rs];
+                    a[u] = a_n[u], b[u] = HASB ? b_n[u] : 1.0;
+                if (k + 1 < W.entry_end) {
+                    Tn = entries[k + 1];
+                    issue(Tn);
+                }
 #pragma unroll
                 for (int u = 0; u < RU; u++)
-                    sum[u] += T.alpha * (T.a_src == 2 ? 1.0 : a[u]) * (T.b_src == 2 ? 1.0 : b[u]);
+                    sum[u] += T.alpha * (T.a_src == 2 ? 1.0 : a[u]) * b[u];
             }
             if (live) {
                 const bool assign = W.ld < 0; // sum pass of the two-stage path: S = ..., not S += ...
@@ -654,10 +688,12 @@ hipError_t launch_outer(const OWork *work, uint32_t n_work, const OEntry *entrie
                         double *out, int rows_in_flight, hipStream_t st) {
     if (n_work == 0)
         return hipSuccess;
+    // the sum passes: sixteen rows in flight (the HASB = false specialisation needs fewer registers, runs more waves per
+    // SIMD and is SLOWER: 127 vs 113 ms on the M=4000 noise list — the transposed blocks live on L1/L2 reuse)
     if (rows_in_flight >= 16)
-        hipLaunchKernelGGL(outer_build_k<16>, dim3((n_work + 3) / 4), dim3(256), 0, st, work, n_work, entries, arena, in, out);
+        hipLaunchKernelGGL((outer_build_k<16, true>), dim3((n_work + 3) / 4), dim3(256), 0, st, work, n_work, entries, arena, in, out);
     else
-        hipLaunchKernelGGL(outer_build_k<4>, dim3((n_work + 3) / 4), dim3(256), 0, st, work, n_work, entries, arena, in, out);
+        hipLaunchKernelGGL((outer_build_k<4, true>), dim3((n_work + 3) / 4), dim3(256), 0, st, work, n_work, entries, arena, in, out);
     return hipGetLastError();
 }
 
