@@ -40,7 +40,7 @@ class PlanStats(C.Structure):
 class PlanOptions(C.Structure):
     _fields_ = [("tile_m", C.c_int32), ("tile_n", C.c_int32), ("kernel", C.c_int32), ("_pad", C.c_int32),
                 ("item_macs", C.c_int64), ("two_stage", C.c_int32), ("scratch_mb", C.c_int32),
-                ("keep_order", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("keep_order", C.c_int32), ("presum", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class B2XError(RuntimeError):
@@ -171,11 +171,12 @@ class Plan:
     """Device-resident GEMM-pair plan (BatchGEMMSeq after precompute(), before post_precompute())."""
 
     def __init__(self, arena, pairs, psi_len, sigma_len, kernel=0, tile_n=0, item_macs=0, two_stage=0, scratch_mb=0,
-                 tile_m=0, keep_order=0):
+                 tile_m=0, keep_order=0, presum=0):
         pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
         opt = PlanOptions()
         opt.kernel, opt.tile_n, opt.item_macs = kernel, tile_n, item_macs
         opt.two_stage, opt.scratch_mb, opt.tile_m, opt.keep_order = two_stage, scratch_mb, tile_m, keep_order
+        opt.presum = presum
         h = C.c_void_p()
         check(lib().b2x_plan_create(C.byref(h), arena._h, C.c_size_t(len(pairs)), _ptr(pairs), C.c_size_t(psi_len),
                                     C.c_size_t(sigma_len), C.byref(opt)))
@@ -265,13 +266,13 @@ def debug_compile_and_emulate_gemms(gemms, in_len, out_len, arena, vin, vout, sc
 
 
 def debug_compile_and_emulate(pairs, psi_len, sigma_len, arena, psi, sigma, scale=1.0, tile_n=0, item_macs=0,
-                              two_stage=0, scratch_mb=0, keep_order=0):
+                              two_stage=0, scratch_mb=0, keep_order=0, presum=0):
     """TEST HOOK (not part of include/b2x.h): compile a plan and evaluate the compiled work list with
     host loops, so the plan compiler can be verified without a GPU.  Returns (stats, fallback)."""
     pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
     opt = PlanOptions()
     opt.tile_n, opt.item_macs = tile_n, item_macs
-    opt.two_stage, opt.scratch_mb, opt.keep_order = two_stage, scratch_mb, keep_order
+    opt.two_stage, opt.scratch_mb, opt.keep_order, opt.presum = two_stage, scratch_mb, keep_order, presum
     st, fb = PlanStats(), C.c_int(0)
     check(lib().b2x_debug_compile_and_emulate(
         C.c_size_t(len(pairs)), _ptr(pairs), C.c_size_t(psi_len), C.c_size_t(sigma_len), C.c_uint64(arena.size),

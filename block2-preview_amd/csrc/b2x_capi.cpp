@@ -144,6 +144,24 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
             if (e != hipSuccess)
                 rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(W scratch): ") + hipGetErrorString(e));
         }
+        if (rc == B2X_OK && !cp.aux_work.empty()) { // operator pre-sums: formed once, into the persistent head of the scratch
+            OWork *dw = nullptr;
+            OEntry *de = nullptr;
+            rc = upload(&dw, cp.aux_work);
+            if (rc == B2X_OK)
+                rc = upload(&de, cp.aux_entries);
+            if (rc == B2X_OK) {
+                hipError_t e = launch_outer(dw, (uint32_t)cp.aux_work.size(), de, arena->dev, p->d_scratch, p->d_scratch, 16, nullptr);
+                if (e == hipSuccess)
+                    e = hipDeviceSynchronize();
+                if (e != hipSuccess)
+                    rc = fail(B2X_ERR_DEVICE, std::string("operator pre-sums: ") + hipGetErrorString(e));
+            }
+            if (dw)
+                (void)hipFree(dw);
+            if (de)
+                (void)hipFree(de);
+        }
         if (rc == B2X_OK && cp.gslab_elems) {
             hipError_t e = hipMalloc((void **)&p->d_gslabs, cp.gslab_elems * sizeof(double));
             if (e != hipSuccess)

@@ -370,6 +370,11 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     uint64_t gg_macs = 0;
     if (!big.empty()) {
         const int TN = kGGTileN;
+        // effective pairs of this path: an operator pre-sum (below) replaces the second operator of a merged pair by a
+        // block in the plan's own buffer (source 2 = scratch, whose first aux_len elements persist across executions)
+        std::vector<b2x_pair> ep(pairs, pairs + n_pairs);
+        std::vector<uint8_t> zsrc(n_pairs, 0), ysrc(n_pairs, 0);
+        uint64_t aux_len = 0;
         const uint64_t budget = (uint64_t)(opt && opt->scratch_mb > 0 ? opt->scratch_mb : 16384) * (1u << 17);
         // work in component order; a super-step closes when the W scratch budget is reached
         // A pair is V += alpha * op(Z) . X . op(Y).  The reference always forms W = X . op(Y) first; the product is
@@ -403,7 +408,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             const uint32_t s0_begin = (uint32_t)out.gitems.size();
             // stage 0: tiles of every W
             for (const PW &pw : cur) {
-                const b2x_pair &p = pairs[win[pw.wi].pair];
+                const b2x_pair &p = ep[win[pw.wi].pair];
                 if (!pw.owner)
                     continue;
                 if (pw.flip) { // W'(m1 x k0) = op(Z)(m1 x k1) . X(k1 x k0)
@@ -411,7 +416,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     for (size_t a = 0; a + 1 < rc.size(); a++)
                         for (size_t b = 0; b + 1 < cc.size(); b++) {
                             GSeg g{};
-                            g.a_src = 0;
+                            g.a_src = zsrc[win[pw.wi].pair];
                             if (p.ta1)
                                 g.a_off = p.z_off + (uint64_t)rc[a], g.a_sr = 1, g.a_sk = p.lda1;
                             else
@@ -434,7 +439,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     for (size_t b = 0; b + 1 < cc.size(); b++) {
                         GSeg g{};
                         g.a_src = 1, g.a_off = p.x_off + (uint64_t)rc[a] * p.lda0, g.a_sr = p.lda0, g.a_sk = 1;
-                        g.b_src = 0;
+                        g.b_src = ysrc[win[pw.wi].pair];
                         if (p.tb0)
                             g.b_off = p.y_off + (uint64_t)cc[b] * p.ldb0, g.b_sk = 1, g.b_sc = p.ldb0;
                         else
@@ -500,12 +505,13 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     std::vector<MK> mk(j - i);
                     for (size_t q = i; q < j; q++) {
                         const Window &w = win[cur[q].wi];
-                        const b2x_pair &p = pairs[w.pair];
+                        const b2x_pair &p = ep[w.pair];
                         MK &m = mk[q - i];
                         m.q = (uint32_t)q;
                         m.k[0] = cur[q].flip, m.k[1] = cur[q].flip ? p.y_off : p.z_off, m.k[2] = w.off;
                         m.k[3] = ((uint64_t)p.m1 << 32) | (uint32_t)p.n0, m.k[4] = cur[q].flip ? (uint64_t)p.k0 : (uint64_t)p.k1;
-                        m.k[5] = cur[q].flip ? (((uint64_t)p.ldb0 << 8) | p.tb0) : (((uint64_t)p.lda1 << 8) | p.ta1);
+                        m.k[5] = cur[q].flip ? (((uint64_t)p.ldb0 << 8) | p.tb0 | ((uint64_t)ysrc[w.pair] << 60))
+                                             : (((uint64_t)p.lda1 << 8) | p.ta1 | ((uint64_t)zsrc[w.pair] << 60));
                     }
                     std::stable_sort(mk.begin(), mk.end(), [](const MK &x, const MK &y) {
                         for (int k = 0; k < 6; k++)
@@ -518,7 +524,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         while (b < mk.size() && std::equal(mk[a].k, mk[a].k + 6, mk[b].k))
                             b++;
                         const size_t gsz = b - a;
-                        const b2x_pair &p0 = pairs[win[cur[mk[a].q].wi].pair];
+                        const b2x_pair &p0 = ep[win[cur[mk[a].q].wi].pair];
                         const bool fl = cur[mk[a].q].flip;
                         const double dim = fl ? (double)p0.n0 : (double)p0.m1;
                         if (gsz > 1 && dim * (double)(gsz - 1) / (double)(gsz + 1) > 64.0) {
@@ -527,7 +533,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             sum_extra += (((uint64_t)srows * scols) + 1) & ~(uint64_t)1;
                             const uint32_t eb = (uint32_t)out.sum_entries.size();
                             for (size_t x = a; x < b; x++) {
-                                const b2x_pair &px = pairs[win[cur[mk[x].q].wi].pair];
+                                const b2x_pair &px = ep[win[cur[mk[x].q].wi].pair];
                                 OEntry e{};
                                 e.a_off = cur[mk[x].q].w_off, e.b_off = 0, e.alpha = px.alpha0 * px.alpha1;
                                 e.a_rs = scols, e.a_cs = 1, e.b_rs = e.b_cs = 0, e.a_src = 1, e.b_src = 2;
@@ -556,7 +562,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     const bool msum = merged_off[q - i] != ~(uint64_t)0; // reads the group's sum, already scaled
                     const uint64_t src_off = msum ? merged_off[q - i] : cur[q].w_off;
                     const Window &w = win[cur[q].wi];
-                    const b2x_pair &p = pairs[w.pair];
+                    const b2x_pair &p = ep[w.pair];
                     uint64_t rel = w.off - c.base;
                     int row0 = (int)(rel / (uint64_t)c.ld), col0 = (int)(rel % (uint64_t)c.ld);
                     int a0 = (int)(std::upper_bound(rc.begin(), rc.end(), row0) - rc.begin()) - 1;
@@ -569,14 +575,14 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             GSeg g{};
                             if (cur[q].flip) { // V[window] += W'(m1 x k0) . op(Y)(k0 x n)
                                 g.a_src = 2, g.a_off = src_off + (uint64_t)r_lo * p.k0, g.a_sr = p.k0, g.a_sk = 1;
-                                g.b_src = 0;
+                                g.b_src = ysrc[w.pair];
                                 if (p.tb0)
                                     g.b_off = p.y_off + (uint64_t)c_lo * p.ldb0, g.b_sk = 1, g.b_sc = p.ldb0;
                                 else
                                     g.b_off = p.y_off + (uint64_t)c_lo, g.b_sk = p.ldb0, g.b_sc = 1;
                                 g.K = p.k0, g.alpha = msum ? 1.0 : p.alpha0 * p.alpha1;
                             } else {
-                            g.a_src = 0;
+                            g.a_src = zsrc[w.pair];
                             if (p.ta1)
                                 g.a_off = p.z_off + (uint64_t)r_lo, g.a_sr = 1, g.a_sk = p.lda1;
                             else
@@ -662,7 +668,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             out.scratch_elems = std::max(out.scratch_elems, used + sum_extra);
             out.gslab_elems = std::max(out.gslab_elems, slab);
             cur.clear();
-            used = 0;
+            used = aux_len;
         };
         struct Cand {
             const Component *c;
@@ -694,7 +700,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             auto group_sizes = [&](bool fl) {
                 std::vector<KeyRef> ks(cand.size());
                 for (size_t q = 0; q < cand.size(); q++)
-                    make_key(pairs[win[cand[q].wi].pair], fl, ks[q].key), ks[q].idx = (uint32_t)q;
+                    make_key(ep[win[cand[q].wi].pair], fl, ks[q].key), ks[q].idx = (uint32_t)q;
                 std::sort(ks.begin(), ks.end(), [](const KeyRef &x, const KeyRef &y) {
                     for (int k = 0; k < 7; k++)
                         if (x.key[k] != y.key[k])
@@ -714,14 +720,88 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             };
             const std::vector<uint32_t> g0 = group_sizes(false), g1 = group_sizes(true);
             for (size_t q = 0; q < cand.size(); q++) {
-                const b2x_pair &p = pairs[win[cand[q].wi].pair];
+                const b2x_pair &p = ep[win[cand[q].wi].pair];
                 const double cur_c = (double)p.k1 * p.k0 * p.n0 / g0[q] + (double)p.m1 * p.k1 * p.n0;
                 const double alt_c = (double)p.m1 * p.k1 * p.k0 / g1[q] + (double)p.m1 * p.k0 * p.n0;
                 cand[q].flip = alt_c < 0.95 * cur_c;
             }
         }
         for (Cand &cd : cand)
-            make_key(pairs[win[cd.wi].pair], cd.flip, cd.key);
+            make_key(ep[win[cd.wi].pair], cd.flip, cd.key);
+        if (allow_flip && opt && opt->presum == 1) {
+            // Operator pre-sums (off by default: +2 % at M=4000, +8 % at M=500, -2 % at M=1000 on the Cr2 plan, for 36 GB
+            // of plan-owned memory at M=4000; the per-step sums of W products above catch most of the same redundancy).  Pairs with the SAME stage-0 product and the SAME psi' window differ only in their second
+            // operator: op(Z_i) for W = X op(Y) (same X, Y), op(Y_i) for W' = op(Z) X (same Z, X).  Their sum
+            // S = sum_i alpha_i op(.)_i depends on the operators alone, so it is formed ONCE, when the plan is created
+            // (element-wise kernel into the persistent head of the plan's scratch), and the group becomes one pair.
+            struct PK {
+                uint64_t k[10];
+                uint32_t q;
+            };
+            std::vector<PK> pk(cand.size());
+            for (size_t q = 0; q < cand.size(); q++) {
+                const Window &w = win[cand[q].wi];
+                const b2x_pair &p = ep[w.pair];
+                std::copy(cand[q].key, cand[q].key + 7, pk[q].k);
+                pk[q].k[7] = w.off, pk[q].k[8] = ((uint64_t)p.m1 << 32) | (uint32_t)p.n0, pk[q].k[9] = (uint64_t)p.ldc1;
+                pk[q].q = (uint32_t)q;
+            }
+            std::stable_sort(pk.begin(), pk.end(), [](const PK &x, const PK &y) {
+                for (int k = 0; k < 10; k++)
+                    if (x.k[k] != y.k[k])
+                        return x.k[k] < y.k[k];
+                return false;
+            });
+            std::vector<uint8_t> dead(cand.size(), 0);
+            for (size_t a2 = 0; a2 < pk.size();) {
+                size_t b2 = a2 + 1;
+                while (b2 < pk.size() && std::equal(pk[a2].k, pk[a2].k + 10, pk[b2].k))
+                    b2++;
+                if (b2 - a2 > 1) {
+                    const uint32_t lead = win[cand[pk[a2].q].wi].pair;
+                    const bool fl = cand[pk[a2].q].flip;
+                    const b2x_pair p0 = ep[lead];
+                    const int srows = fl ? p0.k0 : p0.m1, scols = fl ? p0.n0 : p0.k1; // op(Y) is k0 x n0, op(Z) is m1 x k1
+                    const uint64_t s_off = aux_len;
+                    aux_len += (((uint64_t)srows * scols) + 1) & ~(uint64_t)1;
+                    const uint32_t eb = (uint32_t)out.aux_entries.size();
+                    for (size_t x = a2; x < b2; x++) {
+                        const b2x_pair &px = ep[win[cand[pk[x].q].wi].pair];
+                        OEntry e{};
+                        const bool tr = fl ? px.tb0 : px.ta1;
+                        const int ld = fl ? px.ldb0 : px.lda1;
+                        e.a_off = fl ? px.y_off : px.z_off, e.alpha = px.alpha0 * px.alpha1;
+                        e.a_rs = tr ? 1 : ld, e.a_cs = tr ? ld : 1, e.a_src = 0, e.b_src = 2;
+                        out.aux_entries.push_back(e);
+                        if (x > a2)
+                            dead[pk[x].q] = 1;
+                    }
+                    OWork wk{};
+                    wk.out_off = s_off, wk.ld = -scols, wk.rows = srows, wk.cols = scols, wk.rpt = 16;
+                    wk.entry_begin = eb, wk.entry_end = (uint32_t)out.aux_entries.size();
+                    const uint32_t ntile = (uint32_t)ceil_div(scols, kOuterTileCols) * (uint32_t)ceil_div(srows, 16);
+                    for (uint32_t t0 = 0; t0 < ntile; t0++) {
+                        wk.t_begin = t0, wk.t_end = t0 + 1;
+                        out.aux_work.push_back(wk);
+                    }
+                    b2x_pair &pm = ep[lead];
+                    pm.alpha0 = 1.0, pm.alpha1 = 1.0;
+                    if (fl)
+                        pm.y_off = s_off, pm.tb0 = 0, pm.ldb0 = scols, ysrc[lead] = 2;
+                    else
+                        pm.z_off = s_off, pm.ta1 = 0, pm.lda1 = scols, zsrc[lead] = 2;
+                }
+                a2 = b2;
+            }
+            if (aux_len) {
+                std::vector<Cand> keep;
+                for (size_t q = 0; q < cand.size(); q++)
+                    if (!dead[q])
+                        keep.push_back(cand[q]);
+                cand.swap(keep);
+                used = aux_len;
+            }
+        }
         auto key_less = [](const Cand &x, const Cand &y) {
             for (int k = 0; k < 7; k++)
                 if (x.key[k] != y.key[k])
@@ -733,14 +813,14 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         uint64_t last_off = 0;
         for (size_t q = 0; q < cand.size(); q++) {
             const Cand &cd = cand[q];
-            const b2x_pair &p = pairs[win[cd.wi].pair];
+            const b2x_pair &p = ep[win[cd.wi].pair];
             const bool same = allow_flip && q > 0 && !cur.empty() && !key_less(cand[q - 1], cd) && !key_less(cd, cand[q - 1]);
             if (same) { // shares the product of the previous pair (still in this super-step)
                 cur.push_back(PW{cd.c, cd.wi, last_off, cd.flip, false});
                 continue;
             }
             uint64_t wsz = ((cd.flip ? (uint64_t)p.m1 * p.k0 : (uint64_t)p.k1 * p.n0) + 1) & ~(uint64_t)1;
-            if (used + wsz > budget && !cur.empty())
+            if (used - aux_len + wsz > budget && !cur.empty()) // (the budget bounds the per-step part of the scratch)
                 flush();
             cur.push_back(PW{cd.c, cd.wi, used, cd.flip, true});
             last_off = used;
@@ -1300,6 +1380,8 @@ void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double
     }
     // two-stage path
     std::vector<double> scratch(cp.scratch_elems, 0.0), gslabs(cp.gslab_elems, 0.0);
+    if (!cp.aux_work.empty()) // operator pre-sums (done once at plan creation on the device)
+        emulate_outer_host(cp.aux_work, cp.aux_entries, arena, scratch.data(), scratch.data());
     auto run_item = [&](const GItem &it) {
         std::vector<double> acc((size_t)it.rows * it.cols, 0.0);
         for (uint32_t si = it.seg_begin; si < it.seg_end; si++) {

@@ -143,6 +143,9 @@ struct CompiledPlan {
     // psi' window (scratch -> scratch, element-wise; OWork::ld < 0 marks "assign" instead of "accumulate")
     std::vector<OWork> sum_work;
     std::vector<OEntry> sum_entries;
+    // operator pre-sums, built once when the plan is created (arena -> the first elements of the scratch)
+    std::vector<OWork> aux_work;
+    std::vector<OEntry> aux_entries;
 };
 
 // ---- diagonal build ----------------------------------------------------------------------------------------

@@ -93,7 +93,9 @@ typedef struct b2x_plan_options {
     int32_t scratch_mb;           /* W scratch budget of the two-stage path in MiB (0 = 16384) */
     int32_t keep_order;           /* 1 = always form X.op(Y) first, as the reference does; 0 = per pair the cheaper of
                                      (op(Z).X).op(Y) and op(Z).(X.op(Y)) (same result up to rounding) */
-    int32_t reserved[5];
+    int32_t presum;               /* 1 = also pre-sum, at plan creation, the second operators of pairs that share a stage-0
+                                     product and a psi' window (costs plan-owned memory) */
+    int32_t reserved[4];
 } b2x_plan_options;
 
 const char *b2x_last_error(void);

@@ -239,3 +239,6 @@ def test_shared_products_and_association(gpu, seed, scratch_mb, keep_order):
         assert st["macs_executed"] < st["macs"]
     again, _ = _run(gpu, pf, scratch_mb=scratch_mb, keep_order=keep_order)
     assert np.array_equal(again, sig)
+    if not keep_order:  # operator pre-sums formed at plan creation
+        pre, st3 = _run(gpu, pf, scratch_mb=scratch_mb, presum=1)
+        assert _close(pre, ref), st3

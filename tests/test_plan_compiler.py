@@ -100,3 +100,6 @@ def test_shared_products_and_association(built, seed, scratch_mb, keep_order):
         assert st["macs_executed"] < st["macs"]
     st2 = _check(pf, scratch_mb=scratch_mb, keep_order=keep_order)  # auto routing
     assert st2["macs"] == st["macs"]
+    if not keep_order:  # operator pre-sums on top (second operators of pairs sharing a product and a window)
+        st3 = _check(pf, two_stage=1, scratch_mb=scratch_mb, presum=1)
+        assert st3["macs_executed"] <= st["macs_executed"]
