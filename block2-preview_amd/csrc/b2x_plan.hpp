@@ -3,9 +3,13 @@
 // The reference replays pairs one by one with thread-private copies of psi' and a tree reduction
 // (BatchGEMMSeq::operator(), src/core/batch_gemm.hpp:1606-1682).  On MI355X the list is instead
 // re-segmented by OUTPUT: psi' is cut into tiles, every pair is split into the parts that touch a
-// tile, each tile's part list is chopped into work items of similar cost, and one workgroup per
+// tile, each tile's part list is chopped into work items of similar cost, and one wave / workgroup per
 // item accumulates its parts in registers and writes a partial slab; a second kernel sums the
 // slabs of a tile in fixed order into psi'.  No atomics, bitwise reproducible.
+// Two execution paths: the fused wave kernel (small sectors: W never leaves the registers) and the two-stage
+// grouped-GEMM path (W through an HBM scratch, in super-steps).  On the second path the compiler also uses the algebra
+// of V += alpha op(Z) X op(Y) — association per pair, stage-0 products shared between pairs, sums of products before a
+// common factor — unless b2x_plan_options.keep_order asks for the reference's order.
 #pragma once
 #include "../../include/b2x.h"
 #include <cstdint>

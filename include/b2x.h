@@ -78,8 +78,8 @@ typedef struct b2x_plan_stats {
     uint64_t macs_executed;   /* MACs the kernels really execute: > macs where the fused kernel recomputes stage 0 per row
                                  tile, < macs where the cheaper association of a pair is taken (keep_order = 0) */
     uint64_t dominant_class;  /* kernel class that carries most MACs */
-    uint64_t macs_dominant;   /* MACs executed by the dominant class */
-    uint64_t macs_alg_dominant; /* algorithmic (reference-count) MACs of the pairs in the dominant class */
+    uint64_t macs_dominant;   /* MACs executed by the dominant kernel */
+    uint64_t macs_alg_dominant; /* reference-count MACs (the pairs' m0 n0 k0 + m1 n1 k1) of the work in the dominant kernel */
     uint64_t n_launches;      /* launches of the dominant kernel per execute */
     uint64_t macs_issued;     /* MFMA issue slots x 1024 of the two-stage path incl. tile padding (0 if unused) */
 } b2x_plan_stats;
