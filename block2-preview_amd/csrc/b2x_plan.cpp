@@ -209,8 +209,6 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     };
     std::vector<SectorShape> shapes(comps.size());
     bool any_must = false;
-    const double fused_macs = opt && opt->tile_m > 0 ? 1e8 * opt->tile_m : 2e8;
-    const int kdeep = 64; // inner dimensions beyond this run better through LDS-staged chunks than in the wave kernel
     for (size_t ci = 0; ci < comps.size(); ci++) {
         const Component &c = comps[ci];
         int max_k0 = 0, max_k = 0;
@@ -225,17 +223,17 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         shapes[ci].macs = sector_macs, shapes[ci].max_k = max_k;
         any_must = any_must || shapes[ci].must;
     }
+    any_must = any_must || (double)st.macs > 1e9;
     for (const Component &c : comps) {
         // auto routing: the fused kernel recomputes stage 0 per row tile and keeps W in registers, which
         // pays for sectors that fit one tile; tall / wide / deep ones go to the grouped-GEMM path
-        const SectorShape &sh = shapes[&c - comps.data()];
-        // Sectors taller / wider / deeper than one fused tile must take the grouped-GEMM path.  When a plan has such
-        // sectors it pays that path's fixed costs anyway (three more launches, the W round trip), and then every sector
-        // with real work runs its MFMAs better there; a plan without them (M <= 250 on the Cr2 structure) stays fused
-        // (measured on the bench plan: M=250 2.2 ms all fused vs 3.6 ms all grouped; M=500 8.1 -> 6.9 ms and M=1000
-        // 21.7 -> 20.7 ms with this rule).  "Real work" = many MACs in the sector or a deep inner dimension (the
-        // rotation plans have thousands of one-pair sectors with k of several hundred: M=1000 4.9 -> 3.5 ms).
-        const bool large = sh.must || (any_must && (sh.macs > fused_macs || sh.max_k > kdeep));
+        // Routing is per PLAN: as soon as one sector is taller / wider / deeper than a fused tile, or the plan has more
+        // than 1e9 MACs, EVERY sector takes the grouped-GEMM path: the plan pays that path's fixed costs (two more
+        // launches, the W round trip) once, its kernel runs the MFMAs better, and only there the algebra of DESIGN.md 4.5
+        // applies.  Measured on the Cr2 plan: M=250 1.74 ms fused -> 1.30 ms; M=500 8.0 -> 6.9 ms when the small sectors
+        // followed the large ones; mixed plans (some sectors fused) were never faster than all-grouped.  Small plans
+        // (the N2 / H10 test sizes) stay on the fused wave kernel.
+        const bool large = any_must;
         if (two_stage > 0 || (two_stage == 0 && large)) {
             big.push_back(&c);
             continue;
@@ -319,7 +317,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     // tile store) MFMA-slot units.
     double gg_macs_total = 0;
     for (size_t ci = 0; ci < comps.size(); ci++)
-        if (two_stage > 0 || (two_stage == 0 && (shapes[ci].must || (any_must && (shapes[ci].macs > fused_macs || shapes[ci].max_k > kdeep)))))
+        if (two_stage > 0 || (two_stage == 0 && any_must))
             gg_macs_total += shapes[ci].macs;
     const bool forced = opt && opt->item_macs > 0;
     const double item_cost = forced ? (double)opt->item_macs : std::max((double)total_cost / 10240.0, 131072.0);
