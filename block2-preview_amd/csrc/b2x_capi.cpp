@@ -58,6 +58,7 @@ struct b2x_plan {
     size_t psi_len = 0, sigma_len = 0;
     int dominant_cls = 0;
     bool seg_scaled = false; // single-GEMM list plan (gg_kernel SCALED variant)
+    int gg_tile_n = 128;
 };
 
 static void plan_free(b2x_plan *p) {
@@ -112,6 +113,7 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
     p->fallback = pairs != nullptr && (cp.fallback || p->kernel == 1);
     p->n_pairs = (uint32_t)n_pairs;
     p->seg_scaled = cp.seg_scaled;
+    p->gg_tile_n = cp.gg_tile_n;
     if (p->fallback) {
         std::vector<b2x_pair> pv(pairs, pairs + n_pairs);
         rc = upload(&p->d_pairs, pv);
@@ -354,11 +356,11 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
         HIPCHK(launch_main(k, p->d_parts[k], p->d_items[k], p->n_items[k], p->arena->dev, psi, p->d_slabs, st));
     HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma, scale, st));
     for (const SuperStep &ss : p->steps) {
-        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, st));
+        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st));
         if (ss.sum_end > ss.sum_begin)
             HIPCHK(launch_outer(p->d_sum_work + ss.sum_begin, ss.sum_end - ss.sum_begin, p->d_sum_entries, p->arena->dev,
                                 p->d_scratch, p->d_scratch, 16, st));
-        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, st));
+        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st));
         HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st));
     }
     return B2X_OK;
@@ -416,12 +418,12 @@ int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, 
             HIPCHK(hipEventRecord(e0, st));
             for (const SuperStep &ss : p->steps) {
                 HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi_dev, p->d_scratch,
-                                 p->d_gslabs, p->seg_scaled, st));
+                                 p->d_gslabs, p->seg_scaled, p->gg_tile_n, st));
                 if (ss.sum_end > ss.sum_begin)
                     HIPCHK(launch_outer(p->d_sum_work + ss.sum_begin, ss.sum_end - ss.sum_begin, p->d_sum_entries,
                                         p->arena->dev, p->d_scratch, p->d_scratch, 16, st));
                 HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi_dev, p->d_scratch,
-                                 p->d_gslabs, p->seg_scaled, st));
+                                 p->d_gslabs, p->seg_scaled, p->gg_tile_n, st));
             }
             HIPCHK(hipEventRecord(e1, st));
             HIPCHK(hipEventSynchronize(e1));

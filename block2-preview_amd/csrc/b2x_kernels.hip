@@ -796,18 +796,33 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
 
 // items of all tile-height variants in one grid: v_begin[0] .. v_begin[kGGVariants]
 hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_begin, const double *arena,
-                     const double *psi, double *scratch, double *slabs, bool seg_scaled, hipStream_t st) {
+                     const double *psi, double *scratch, double *slabs, bool seg_scaled, int tile_n, hipStream_t st) {
     const uint32_t n = v_begin[kGGVariants] - v_begin[0];
     if (n == 0)
         return hipSuccess;
     // chunk depth 16: a 32-deep chunk halves the barriers (+2 % on uniform 1024^3 pairs) but pads every K to 32 and
     // spills at 256 VGPRs (-2 % on the M=4000 plan)
-    if (seg_scaled)
-        hipLaunchKernelGGL((gg_kernel<kGGCF, kGGTileN / (16 * kGGCF), 16, true>), dim3(n), dim3(kGGTileN * 4 / kGGCF), 0, st, segs,
-                           items + v_begin[0], arena, psi, scratch, slabs);
-    else
-        hipLaunchKernelGGL((gg_kernel<kGGCF, kGGTileN / (16 * kGGCF), 16, false>), dim3(n), dim3(kGGTileN * 4 / kGGCF), 0, st, segs,
-                           items + v_begin[0], arena, psi, scratch, slabs);
+#define B2X_GG_LAUNCH(NWV, SBV)                                                                                        \
+    hipLaunchKernelGGL((gg_kernel<kGGCF, NWV, 16, SBV>), dim3(n), dim3(NWV * 64), 0, st, segs, items + v_begin[0], arena, \
+                       psi, scratch, slabs)
+    const int nw = tile_n / (16 * kGGCF); // waves per workgroup: 4 (128-column tiles), 2 or 1 (narrow sectors)
+    if (nw >= 4) {
+        if (seg_scaled)
+            B2X_GG_LAUNCH(4, true);
+        else
+            B2X_GG_LAUNCH(4, false);
+    } else if (nw == 2) {
+        if (seg_scaled)
+            B2X_GG_LAUNCH(2, true);
+        else
+            B2X_GG_LAUNCH(2, false);
+    } else {
+        if (seg_scaled)
+            B2X_GG_LAUNCH(1, true);
+        else
+            B2X_GG_LAUNCH(1, false);
+    }
+#undef B2X_GG_LAUNCH
     return hipGetLastError();
 }
 

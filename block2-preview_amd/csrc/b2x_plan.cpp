@@ -367,7 +367,18 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     // ---- two-stage path: W = alpha X op(Y) to scratch, then psi' tiles += op(Z) W ---------------
     uint64_t gg_macs = 0;
     if (!big.empty()) {
-        const int TN = kGGTileN;
+        // narrow psi' sectors (small bond dimensions) waste most of a 128-column tile: such plans use 2-wave workgroups
+        // (MAC-weighted mean output width of the pairs; measured on the Cr2 plan: 64-column tiles / 2-wave workgroups win
+        // below ~300 — M=250 1.30 -> 0.84 ms, M=500 3.5 -> 2.6 ms —, tie at 240 (M=1000), 128 columns win above)
+        double wsum = 0, wn = 0;
+        for (const Component *c : big)
+            for (uint32_t wi = c->w_begin; wi < c->w_end; wi++) {
+                const b2x_pair &p = pairs[win[wi].pair];
+                const double w = (double)p.m0 * p.n0 * p.k0 + (double)p.m1 * p.n1 * p.k1;
+                wsum += w, wn += w * p.n0;
+            }
+        const int TN = (wsum > 0 && wn / wsum < 300.0) ? 64 : kGGTileN;
+        out.gg_tile_n = TN;
         // effective pairs of this path: an operator pre-sum (below) replaces the second operator of a merged pair by a
         // block in the plan's own buffer (source 2 = scratch, whose first aux_len elements persist across executions)
         std::vector<b2x_pair> ep(pairs, pairs + n_pairs);
@@ -1010,7 +1021,13 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     double eff_macs = 0;
     for (size_t i = 0; i < n_eff; i++)
         eff_macs += (double)eff[i].m * eff[i].n * eff[i].k;
-    const int TN = kGGTileN;
+    double wsum = 0, wn = 0; // tile width by the MAC-weighted mean output width of the records, as in compile_plan
+    for (size_t i = 0; i < n_eff; i++) {
+        const double w = (double)eff[i].m * eff[i].n * eff[i].k;
+        wsum += w, wn += w * eff[i].n;
+    }
+    const int TN = (wsum > 0 && wn / wsum < 300.0) ? 64 : kGGTileN;
+    out.gg_tile_n = TN;
     // item size as in compile_plan: ~8 rounds over the workgroup slots, between 2e6 and 6e7 MFMA-slot units
     const double per_item = opt && opt->item_macs > 0 ? (double)opt->item_macs : std::min(6.0e7, std::max(2.0e6, eff_macs / 4096.0));
     SuperStep ss{};

@@ -143,6 +143,7 @@ struct CompiledPlan {
     bool fallback = false; // windows could not be segmented -> generic atomic kernel
     std::string fallback_reason;
     bool seg_scaled = false; // single-GEMM list: segments carry their own alpha (gg_kernel SCALED variant)
+    int gg_tile_n = kGGTileN; // column width of the grouped-GEMM tiles of this plan: 128 (4 waves) or 64 (2 waves)
     // sum pass of the two-stage path: S = sum_i alpha_i W_i for pairs that multiply the same operator block into the same
     // psi' window (scratch -> scratch, element-wise; OWork::ld < 0 marks "assign" instead of "accumulate")
     std::vector<OWork> sum_work;
