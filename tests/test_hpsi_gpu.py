@@ -215,7 +215,16 @@ def test_full_size_m4000_properties(gpu):
     scale = float(hz.abs().max())
     assert float((hz - (0.3 * hx - 1.7 * hy)).abs().max()) <= 1e-11 * scale
     assert torch.equal(apply(x), hx)  # fixed summation order
+    assert plan.stats["macs_executed"] < 0.7 * full.macs  # association / sharing / sums of products
     plan.close()
+    # the same plan replayed pair by pair in the reference's order of operations
+    ref_order = gpu.Plan(arena, full.pairs, full.psi_len, full.sigma_len, keep_order=1)
+    assert ref_order.stats["macs_executed"] == full.macs
+    out = torch.zeros(full.sigma_len, dtype=torch.float64, device=dev)
+    ref_order.execute_device(x.data_ptr(), out.data_ptr(), 1.0, s)
+    torch.cuda.synchronize()
+    assert float((out - hx).abs().max()) <= 1e-11 * float(hx.abs().max())
+    ref_order.close()
     generic = gpu.Plan(arena, full.pairs, full.psi_len, full.sigma_len, kernel=1)
     out = torch.zeros(full.sigma_len, dtype=torch.float64, device=dev)
     generic.execute_device(x.data_ptr(), out.data_ptr(), 1.0, s)
