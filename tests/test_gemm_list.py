@@ -137,6 +137,49 @@ def test_compiled_gemm_list_random(built, seed, item_macs):
     assert np.allclose(out, ref, rtol=0, atol=1e-10 * max(1.0, np.abs(ref).max()))
 
 
+def shared_operator_list(rng, tb, proportional, k=37, n=53, n_ops=12, ms=(40, 24, 31)):
+    """n_ops operator blocks (k x n, stored transposed if tb) applied to len(ms) psi blocks, one output window each; the
+    coefficient vector of psi block j is (0.5 + j) x a common vector, or independent"""
+    from block2_preview_amd.planfile import GEMM_DTYPE
+
+    ldb = (k if tb else n) + 2
+    op_len = (n if tb else k) * ldb
+    x_off, c_off, in_len, out_len = [], [], 0, 0
+    for m in ms:
+        x_off.append(in_len), c_off.append(out_len)
+        in_len, out_len = in_len + m * k, out_len + m * n
+    base = rng.standard_normal(n_ops)
+    g = np.zeros(n_ops * len(ms), GEMM_DTYPE)
+    for j, m in enumerate(ms):
+        al = base * (0.5 + j) if proportional else rng.standard_normal(n_ops)
+        for i in range(n_ops):
+            g[j * n_ops + i] = (m, n, k, k, ldb, n, 0, tb, 1, 0, 0, al[i], x_off[j], i * op_len, c_off[j])
+    rng.shuffle(g)
+    return g, in_len, out_len, n_ops * op_len
+
+
+@pytest.mark.parametrize("tb", [0, 1])
+def test_operator_sums_are_shared_between_psi_blocks(built, tb):
+    """The same operator blocks applied to several psi blocks with proportional coefficient vectors (the coupling factor
+    of the psi block) need ONE sum S = sum_i alpha_i B_i; independent coefficient vectors need one sum per psi block."""
+    from block2_preview_amd import capi
+
+    rng = np.random.default_rng(11 + tb)
+    k, n, n_ops, ms = 37, 53, 12, (40, 24, 31)
+    res = {}
+    for proportional in (True, False):
+        g, in_len, out_len, arena_len = shared_operator_list(rng, tb, proportional, k, n, n_ops, ms)
+        arena, vin = rng.standard_normal(arena_len), rng.standard_normal(in_len)
+        ref, out = np.zeros(out_len), np.zeros(out_len)
+        numpy_gemm_list(g, arena, vin, ref)
+        st = capi.debug_compile_and_emulate_gemms(g, in_len, out_len, arena, vin, out)
+        assert np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max()
+        assert st["macs_executed"] == sum(m * n * k for m in ms)  # one product per psi block
+        res[proportional] = st["device_bytes"]
+    per_sum = ((k * n + 1) & ~1) * 8 + n_ops * 48  # S + its entry list
+    assert res[False] - res[True] >= 2 * per_sum  # two sums fewer
+
+
 def test_gemm_list_validation(built):
     from block2_preview_amd import capi
     from block2_preview_amd.planfile import GEMM_DTYPE

@@ -10,7 +10,7 @@ from conftest import GOLDEN
 from block2_preview_amd import synth
 from block2_preview_amd.planfile import read_gemm_list
 from oracle import oracle
-from test_gemm_list import numpy_gemm_list, pnoise_files, random_gemm_list
+from test_gemm_list import numpy_gemm_list, pnoise_files, random_gemm_list, shared_operator_list
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-12
@@ -77,6 +77,26 @@ def test_cr2_structure_scaled(gpu, fn, f):
     out, st = _run(gpu, gl, arena, vin)
     assert st["macs"] == gl.macs
     assert _close(out, ref)
+
+
+@pytest.mark.parametrize("tb,proportional", [(0, True), (1, True), (1, False)])
+def test_shared_operator_sums(gpu, tb, proportional):
+    """operator sums shared between psi blocks (proportional coefficient vectors) or one per block: vs numpy, and vs the
+    record-by-record replay of the same list"""
+    from types import SimpleNamespace
+
+    rng = np.random.default_rng(21 + tb)
+    g, in_len, out_len, arena_len = shared_operator_list(rng, tb, proportional, k=150, n=210, n_ops=9, ms=(130, 70, 16))
+    gl = SimpleNamespace(gemms=g, in_len=in_len, out_len=out_len)
+    arena, vin = rng.standard_normal(arena_len), rng.standard_normal(in_len)
+    ref = np.zeros(out_len)
+    numpy_gemm_list(g, arena, vin, ref)
+    out, st = _run(gpu, gl, arena, vin)
+    assert st["macs_executed"] * 9 == st["macs"]
+    assert _close(out, ref)
+    out1, st1 = _run(gpu, gl, arena, vin, keep_order=1)
+    assert st1["macs_executed"] == st1["macs"]
+    assert _close(out1, ref)
 
 
 def test_linearity_large(gpu):
