@@ -12,7 +12,7 @@ import numpy as np
 from .planfile import GEMM_DTYPE, OUTER_TERM_DTYPE, PAIR_DTYPE
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libb2x.so")
+LIB_PATH = os.environ.get("B2X_LIB") or os.path.join(_HERE, "libb2x.so")  # B2X_LIB: an experimental build (kernel probes)
 
 # every symbol include/b2x.h declares (checked by tests/test_capi_symbols.py)
 DECLARED_SYMBOLS = [

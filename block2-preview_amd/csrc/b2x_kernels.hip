@@ -224,7 +224,8 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     constexpr int NG = TM * KC / 2;      // 16-byte granules per chunk
     constexpr int NI = (NG + NT - 1) / NT; // DMA instructions per thread per chunk
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6); // in an SGPR: the LDS-DMA destinations (M0) stay scalar
     const int g = lane >> 4, c = lane & 15;
 
     v4d acc[TMF][CF];
@@ -235,94 +236,106 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
             acc[f][q] = v4d{0.0, 0.0, 0.0, 0.0};
 
     double bnxt[CF][KS], bcur[CF][KS];
-    // ---- per-segment state: 32-bit element offsets from wave-uniform bases --------------------------
+    // ---- per-segment state ---------------------------------------------------------------------------
+    // The MFMA f64 pipe and the vector ALU of a SIMD do not run side by side: every VALU instruction between two MFMAs
+    // costs matrix time (probe: the same MFMA stream ran at 74.5 TFLOP/s with no per-chunk VALU work, 68 with the
+    // copies and control of this loop, 62 with per-load address arithmetic).  A load address is therefore a SCALAR base
+    // that advances with the chunk (SALU) plus a per-lane byte offset (va, vb) that is computed when a segment is
+    // entered and again only for a segment's last, partial chunk, whose k tail needs clamping.
     const double *sA = arena, *sB = arena;
-    uint32_t aoff[NI];   // per DMA instruction: row part of the source offset
-    uint32_t akq[NI];    // per DMA instruction: k (rowmaj: first k of the granule; kmaj: k of the granule)
-    uint32_t boff[CF];   // clamped column * b_sc
-    uint32_t colmask = 0, akmax = 0, bkmax = 0, astep = 1;
+    uint32_t va[NI];     // per DMA instruction: byte offset of this lane's granule from the chunk's A base
+    uint32_t vb[CF][KS]; // byte offset of this lane's B element from the k-step's B base
+    uint32_t astep = 1, bstep = 1;
+    uint32_t bmask = 0;  // B mask of the chunk that is fetched next (columns; k tail)
+    int sK = 0;
+    bool tail = false;   // the offsets in va / vb are those of the partial last chunk
     double salpha = 1.0; // SB (single-GEMM lists): per-segment factor, folded into the B fragments
-    bool s_kmaj = false, cols_full = false;
-#pragma unroll
-    for (int j = 0; j < NI; j++)
-        aoff[j] = 0, akq[j] = 0;
+    bool s_kmaj = false, cols_full = false, bmasked = false;
 
+    // per-lane offsets of the chunk at k offset kb of segment S: unclamped for a full chunk (valid for every full chunk
+    // of the segment), clamped to the last k for the partial one
+    auto lane_offsets = [&](const GSeg &S, int kb, bool part) __attribute__((always_inline)) {
+        const uint32_t akmax = (uint32_t)(S.K - 1 - kb) * astep; // relative to the chunk base
+#pragma unroll
+        for (int j = 0; j < NI; j++) {
+            // granule G of the LDS image is written by lane `lane` of DMA instruction (wave, j)
+            const int G = (wave * NI + j) * 64 + lane;
+            uint32_t ro, ko;
+            if (s_kmaj) { // fragment-major image [f][k][16 rows]: granule = rows (f*16 + 2p, +1) of one k
+                const int f = G / (KC * 8), kl = (G % (KC * 8)) >> 3, p2 = G & 7;
+                ro = (uint32_t)min(f * 16 + 2 * p2, S.mr - 1);
+                ko = (uint32_t)kl * astep;
+            } else { // image [TM rows][KC k]; granule slot gs of a row holds k = 2*(gs ^ swz(row)), +1
+                const int row = G / (KC / 2), gs = G % (KC / 2);
+                const int swz = KC == 16 ? ((row >> 1) & 7) : (row & 15);
+                ro = (uint32_t)min(row, S.mr - 1) * (uint32_t)S.a_sr;
+                ko = (uint32_t)(2 * (gs ^ swz));
+            }
+            va[j] = (ro + (part ? min(ko, akmax) : ko)) * 8u;
+        }
+        const uint32_t bkmax = (uint32_t)(S.K - 1 - kb) * bstep;
+        bmask = 0;
+#pragma unroll
+        for (int q = 0; q < CF; q++) {
+            const int cc = wave * (CF * 16) + q * 16 + c - S.tc0;
+            const bool in = cc >= 0 && cc < S.nc;
+            const uint32_t co = (uint32_t)min(max(cc, 0), S.nc - 1) * (uint32_t)S.b_sc;
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                // full chunk: the k-step's 4 s rows are in the scalar base; partial chunk: base = chunk start
+                vb[q][s] = (co + (part ? min((uint32_t)(4 * s + g) * bstep, bkmax) : (uint32_t)g * bstep)) * 8u;
+                bmask |= (uint32_t)(in && (!part || kb + 4 * s + g < S.K)) << (q * KS + s);
+            }
+        }
+        tail = part;
+        bmasked = part || !cols_full;
+    };
     auto enter = [&, arena, psi, scratch](const GSeg &S) __attribute__((always_inline)) {
         sA = (S.a_src == 0 ? arena : (S.a_src == 1 ? psi : scratch)) + S.a_off;
         sB = (S.b_src == 0 ? arena : (S.b_src == 1 ? psi : scratch)) + S.b_off;
         s_kmaj = (S.a_sk != 1);
         cols_full = (S.tc0 == 0 && S.nc >= item.cols);
-        astep = (uint32_t)S.a_sk;
+        astep = (uint32_t)S.a_sk, bstep = (uint32_t)S.b_sk;
+        sK = S.K;
         if (SB)
             salpha = S.alpha;
-        akmax = (uint32_t)(S.K - 1) * astep, bkmax = (uint32_t)(S.K - 1) * (uint32_t)S.b_sk;
-#pragma unroll
-        for (int j = 0; j < NI; j++) {
-            // granule G of the LDS image is written by lane `lane` of DMA instruction (wave, j)
-            const int G = (wave * NI + j) * 64 + lane;
-            if (s_kmaj) { // fragment-major image [f][k][16 rows]: granule = rows (f*16 + 2p, +1) of one k
-                const int f = G / (KC * 8), kl = (G % (KC * 8)) >> 3, p2 = G & 7;
-                aoff[j] = (uint32_t)min(f * 16 + 2 * p2, S.mr - 1);
-                akq[j] = (uint32_t)kl * astep;
-            } else { // image [TM rows][KC k]; granule slot gs of a row holds k = 2*(gs ^ swz(row)), +1
-                const int row = G / (KC / 2), gs = G % (KC / 2);
-                const int swz = KC == 16 ? ((row >> 1) & 7) : (row & 15);
-                aoff[j] = (uint32_t)min(row, S.mr - 1) * (uint32_t)S.a_sr;
-                akq[j] = (uint32_t)(2 * (gs ^ swz));
-            }
-        }
-        colmask = 0;
-#pragma unroll
-        for (int q = 0; q < CF; q++) {
-            int cc = wave * (CF * 16) + q * 16 + c - S.tc0;
-            colmask |= (uint32_t)(cc >= 0 && cc < S.nc) << q;
-            boff[q] = (uint32_t)min(max(cc, 0), S.nc - 1) * (uint32_t)S.b_sc;
-        }
+        lane_offsets(S, 0, S.K < KC);
     };
-    uint32_t bmask = 0;
-    bool bmasked = false;
-    // issue the DMA of the A chunk at k offset kb into LDS buffer `As`, and the B loads into bnxt
-    // the A half of a fetch: this wave's share of the chunk's LDS-DMA
+    // the A half of a fetch: this wave's share of the LDS-DMA of the chunk at k offset kb into LDS buffer `As`
     auto fetch_dma = [&](int kb, double *As) __attribute__((always_inline)) {
-        const uint32_t kbo = (uint32_t)kb * astep;
+        const char *ba = (const char *)(sA + (uint64_t)((uint32_t)kb * astep));
 #pragma unroll
-        for (int j = 0; j < NI; j++) {
-            if (NG % NT == 0 || (wave * NI + j) * 64 < NG) { // whole DMA instruction inside the image
-                const uint32_t off = aoff[j] + min(kbo + akq[j], akmax);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(sA + off),
+        for (int j = 0; j < NI; j++)
+            if (NG % NT == 0 || (wave * NI + j) * 64 < NG) // whole DMA instruction inside the image
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ba + va[j]),
                                                  (__attribute__((address_space(3))) void *)(As + (wave * NI + j) * 128),
                                                  16, 0, 0);
-            }
+    };
+    // ... and the B fragments of the same chunk into bnxt
+    auto fetch = [&](int kb, double *As) __attribute__((always_inline)) {
+        fetch_dma(kb, As);
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const char *bb = (const char *)(sB + (uint64_t)((uint32_t)(kb + (tail ? 0 : 4 * s)) * bstep));
+#pragma unroll
+            for (int q = 0; q < CF; q++)
+                bnxt[q][s] = *(const double *)(bb + vb[q][s]);
         }
     };
-    auto fetch = [&](const GSeg &S, int kb, double *As) __attribute__((always_inline)) {
-        fetch_dma(kb, As);
-        const uint32_t bstep = (uint32_t)S.b_sk;
-#pragma unroll
-        for (int q = 0; q < CF; q++) {
-            uint32_t ko = (uint32_t)(kb + g) * bstep;
-#pragma unroll
-            for (int s = 0; s < KS; s++) {
-                bnxt[q][s] = sB[boff[q] + min(ko, bkmax)];
-                ko += 4 * bstep;
-            }
-        }
-        bmasked = !cols_full || kb + KC > S.K; // the k tail is neutralised on the B side
-        if (bmasked) {
-            bmask = 0;
+    auto commit = [&]() __attribute__((always_inline)) {
+        if (!bmasked) { // (wave-uniform) the common case: a register copy, no mask arithmetic
 #pragma unroll
             for (int q = 0; q < CF; q++)
 #pragma unroll
                 for (int s = 0; s < KS; s++)
-                    bmask |= (uint32_t)(((colmask >> q) & 1) && kb + 4 * s + g < S.K) << (q * KS + s);
+                    bcur[q][s] = SB ? bnxt[q][s] * salpha : bnxt[q][s];
+            return;
         }
-    };
-    auto commit = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < CF; q++)
 #pragma unroll
             for (int s = 0; s < KS; s++)
-                bcur[q][s] = (!bmasked || ((bmask >> (q * KS + s)) & 1)) ? (SB ? bnxt[q][s] * salpha : bnxt[q][s]) : 0.0;
+                bcur[q][s] = ((bmask >> (q * KS + s)) & 1) ? (SB ? bnxt[q][s] * salpha : bnxt[q][s]) : 0.0;
     };
     // the MFMA block: all TMF x CF fragments, branch-free
     // Pin the issue order inside the MFMA block: LDS reads run LEAD fragments ahead of the MFMAs that consume
@@ -389,7 +402,8 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
                 if (more && nsi != hi) {
                     S = segs[nsi];
                     enter(S);
-                }
+                } else if (more && nkb + KC > S.K)
+                    lane_offsets(S, nkb, true); // the segment's partial last chunk
                 if (!more)
                     break;
                 fetch_dma(nkb, lds + (buf ^ 1) * ABUF);
@@ -406,7 +420,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         GSeg Sn = segs[min(si + 1, item.seg_end - 1)];
         int kb = 0, buf = 0;
         enter(S);
-        fetch(S, 0, lds);
+        fetch(0, lds);
         commit();
         bool cur_kmaj = s_kmaj;
         __syncthreads(); // drains the DMA (vmcnt(0)) and publishes the image
@@ -432,9 +446,10 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
                     S = Sn; // descriptor prefetched one segment ahead: no scalar-load latency at the switch
                     Sn = segs[min(nsi + 1, item.seg_end - 1)];
                     enter(S);
-                }
+                } else if (more && nkb + KC > S.K)
+                    lane_offsets(S, nkb, true); // the segment's partial last chunk
                 if (more)
-                    fetch(S, nkb, lds + (buf ^ 1) * ABUF);
+                    fetch(nkb, lds + (buf ^ 1) * ABUF);
             }
             __builtin_amdgcn_sched_barrier(0); // loads issued; nothing below may move above them
             compute(lds + buf * ABUF, cur_kmaj, H0{}, NH0{});
@@ -444,9 +459,10 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
                     S = Sn;
                     Sn = segs[min(nsi + 1, item.seg_end - 1)];
                     enter(S);
-                }
+                } else if (more && nkb + KC > S.K)
+                    lane_offsets(S, nkb, true);
                 if (more)
-                    fetch(S, nkb, lds + (buf ^ 1) * ABUF);
+                    fetch(nkb, lds + (buf ^ 1) * ABUF);
             }
             __builtin_amdgcn_sched_barrier(0);
             compute(lds + buf * ABUF, cur_kmaj, H1{}, NH1{});

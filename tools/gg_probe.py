@@ -24,11 +24,18 @@ p["v_off"] = ((np.arange(n) // 2) % nsec) * d * d
 p["y_off"] = np.arange(n) * 2 * d * d
 p["z_off"] = np.arange(n) * 2 * d * d + d * d
 dev = torch.device("cuda", 0)
-arena_t = torch.rand(2 * n * d * d, dtype=torch.float64, device=dev)
-psi = torch.rand(nsec * d * d, dtype=torch.float64, device=dev)
+if os.environ.get("B2X_PROBE_DATA") == "ones":  # power probe: constant operands toggle few bits in the MFMA pipe
+    arena_t = torch.ones(2 * n * d * d, dtype=torch.float64, device=dev)
+    psi = torch.ones(nsec * d * d, dtype=torch.float64, device=dev)
+elif os.environ.get("B2X_PROBE_DATA") == "zeros":
+    arena_t = torch.zeros(2 * n * d * d, dtype=torch.float64, device=dev)
+    psi = torch.zeros(nsec * d * d, dtype=torch.float64, device=dev)
+else:
+    arena_t = torch.rand(2 * n * d * d, dtype=torch.float64, device=dev)
+    psi = torch.rand(nsec * d * d, dtype=torch.float64, device=dev)
 sig = torch.zeros(nsec * d * d, dtype=torch.float64, device=dev)
 arena = capi.Arena.adopt_device(arena_t.data_ptr(), arena_t.numel(), keep=arena_t)
-plan = capi.Plan(arena, p, psi.numel(), sig.numel(), two_stage=two)
+plan = capi.Plan(arena, p, psi.numel(), sig.numel(), two_stage=two, item_macs=int(float(os.environ.get('B2X_ITEM_MACS', '0'))))
 st = plan.stats
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(2):

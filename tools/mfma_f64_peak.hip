@@ -39,5 +39,9 @@ int main() {
         run<4>(w, 5000);
         run<16>(w, 2000);
     }
+    // sustained: the same kernel for ~0.25 s and ~1 s (power management settles within tens of ms)
+    run<4>(2, 1000000);
+    run<4>(2, 4000000);
+    run<4>(4, 1000000);
     return 0;
 }
