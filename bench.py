@@ -15,7 +15,7 @@ does with MPI (src/core/parallel_tensor_functions.hpp:51-55).
 `value` counts the ALGORITHMIC flops of the workload, 2 x the reference's nflop (2 * sum over pairs of
 m0 n0 k0 + m1 n1 k1, the reference's order of operations) — the BASELINE metric.  The plan compiler executes fewer: per
 pair it takes the cheaper association of op(Z).X.op(Y) and it computes a stage-0 product shared by several pairs once
-(`roofline.executed_over_algorithmic_macs`, 0.65 on this plan; same result up to rounding, nothing is cached across
+(`roofline.executed_over_algorithmic_macs`, 0.58 on this plan; same result up to rounding, nothing is cached across
 steps).  `roofline.achieved` / `frac` are the HARDWARE roofline — executed flops of the dominant kernel / its time —
 and `roofline.algorithmic_tflops` is the same kernel time in the reference's flop count (it may exceed the MFMA peak).
 `--keep-order 1` replays the reference's order pair by pair (executed == algorithmic).
@@ -232,8 +232,9 @@ def main():
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20) x%d -> M=%d"
-                                   % (args.scale, M),
+            "config": {"workload": ("Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20) x%d -> M=%d"
+                                    % (args.scale, M)) if args.struct.endswith("cr2_su2_m250_sw1_site20.struct.npz") else
+                                   ("pair plan %s x%d -> M=%d" % (os.path.basename(args.struct), args.scale, M)),
                        "pairs": int(len(full.pairs)), "tmac_per_step": round(full.macs / 1e12, 3),
                        "psi_len": int(full.psi_len), "operator_gb": round(full.arena_len * 8 / 1e9, 1),
                        "parallelism": "sum-MPO x%d" % world},

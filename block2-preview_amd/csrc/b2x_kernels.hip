@@ -247,7 +247,6 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     uint32_t vb[CF][KS]; // byte offset of this lane's B element from the k-step's B base
     uint32_t astep = 1, bstep = 1;
     uint32_t bmask = 0;  // B mask of the chunk that is fetched next (columns; k tail)
-    int sK = 0;
     bool tail = false;   // the offsets in va / vb are those of the partial last chunk
     double salpha = 1.0; // SB (single-GEMM lists): per-segment factor, folded into the B fragments
     bool s_kmaj = false, cols_full = false, bmasked = false;
@@ -296,7 +295,6 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         s_kmaj = (S.a_sk != 1);
         cols_full = (S.tc0 == 0 && S.nc >= item.cols);
         astep = (uint32_t)S.a_sk, bstep = (uint32_t)S.b_sk;
-        sK = S.K;
         if (SB)
             salpha = S.alpha;
         lane_offsets(S, 0, S.K < KC);
@@ -821,22 +819,17 @@ hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_beg
 #define B2X_GG_LAUNCH(NWV, SBV)                                                                                        \
     hipLaunchKernelGGL((gg_kernel<kGGCF, NWV, 16, SBV>), dim3(n), dim3(NWV * 64), 0, st, segs, items + v_begin[0], arena, \
                        psi, scratch, slabs)
-    const int nw = tile_n / (16 * kGGCF); // waves per workgroup: 4 (128-column tiles), 2 or 1 (narrow sectors)
+    const int nw = tile_n / (16 * kGGCF); // waves per workgroup: 4 (128-column tiles) or 2 (narrow sectors)
     if (nw >= 4) {
         if (seg_scaled)
             B2X_GG_LAUNCH(4, true);
         else
             B2X_GG_LAUNCH(4, false);
-    } else if (nw == 2) {
+    } else { // (the plan compiler picks 128- or 64-column tiles)
         if (seg_scaled)
             B2X_GG_LAUNCH(2, true);
         else
             B2X_GG_LAUNCH(2, false);
-    } else {
-        if (seg_scaled)
-            B2X_GG_LAUNCH(1, true);
-        else
-            B2X_GG_LAUNCH(1, false);
     }
 #undef B2X_GG_LAUNCH
     return hipGetLastError();
