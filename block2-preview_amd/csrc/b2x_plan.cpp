@@ -315,7 +315,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     // than the chip can run at once only buy tail balance at the price of reduce traffic (at M=250 the reduce was 38 %
     // of an H.psi with 32 768 wave items: 2.2 ms; ~10 000 items: 1.75 ms; ~4 000: 2.6 ms, too few to balance).  Fused
     // classes: about three wave items per wave slot (256 CUs x 4 SIMDs x 3-4 waves).  Grouped GEMM: enough workgroup items for ~8 rounds over the 512 workgroup
-    // slots, between 2e6 (small plans need the parallelism) and 6e7 (large plans: fewer, longer items amortise the
+    // slots, between 2e6 (small plans need the parallelism) and 3e7 (large plans: fewer, longer items amortise the
     // tile store) MFMA-slot units.
     double gg_macs_total = 0;
     for (size_t ci = 0; ci < comps.size(); ci++)
@@ -323,7 +323,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             gg_macs_total += shapes[ci].macs;
     const bool forced = opt && opt->item_macs > 0;
     const double item_cost = forced ? (double)opt->item_macs : std::max((double)total_cost / 10240.0, 131072.0);
-    const double step_item_cost = forced ? (double)opt->item_macs : std::min(6.0e7, std::max(2.0e6, gg_macs_total / 4096.0));
+    // (upper bound 3e7: at M=1000 6e7 left too few items per launch, 12.6 -> 11.5 ms; no difference at M >= 2000)
+    const double step_item_cost = forced ? (double)opt->item_macs : std::min(3.0e7, std::max(2.0e6, gg_macs_total / 4096.0));
     uint64_t slab = 0;
     for (size_t t = 0; t < htiles.size(); t++) {
         HostTile &ht = htiles[t];
