@@ -118,13 +118,11 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
         std::vector<b2x_pair> pv(pairs, pairs + n_pairs);
         rc = upload(&p->d_pairs, pv);
     } else {
-        size_t best = 0;
         for (int k = 0; k < kNumClasses && rc == B2X_OK; k++) {
             rc = upload(&p->d_parts[k], cp.cls[k].parts);
             if (rc == B2X_OK)
                 rc = upload(&p->d_items[k], cp.cls[k].items);
             p->n_items[k] = (uint32_t)cp.cls[k].items.size();
-            (void)best;
         }
         p->dominant_cls = (int)cp.stats.dominant_class;
         if (rc == B2X_OK)

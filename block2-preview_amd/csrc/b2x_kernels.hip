@@ -549,7 +549,6 @@ __global__ __launch_bounds__(256) void hpsi_generic(const b2x_pair *__restrict__
     constexpr int WC = 2048; // doubles of W kept in LDS per chunk
     __shared__ double Ws[WC];
     const int n = p.n0;
-    const int rows_per = max(1, WC / n) < p.m0 ? max(1, WC / n) : p.m0;
     const double *X = psi + p.x_off, *Y = arena + p.y_off, *Z = arena + p.z_off;
     double *V = sigma + p.v_off;
     // n may exceed WC: then process column chunks too
@@ -580,7 +579,6 @@ __global__ __launch_bounds__(256) void hpsi_generic(const b2x_pair *__restrict__
             }
         }
     }
-    (void)rows_per;
 }
 
 // ------------------------------------ diagonal of H_eff ------------------------------------------

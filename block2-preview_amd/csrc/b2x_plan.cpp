@@ -610,8 +610,6 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             gg_macs += (uint64_t)g.mr * g.nc * g.K;
                         }
                 }
-                double comp_cost = std::accumulate(tcost.begin(), tcost.end(), 0.0);
-                (void)comp_cost;
                 for (int a = 0; a < nrt; a++)
                     for (int b = 0; b < nct; b++) {
                         size_t t = (size_t)a * nct + b;
@@ -1416,7 +1414,6 @@ void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double
     std::vector<double> slabs(cp.slab_elems, 0.0);
     for (int k = 0; k < kNumClasses; k++) {
         const ClassWork &cw = cp.cls[k];
-        const int TN = kClasses[k].nw * 16;
         for (const DItem &it : cw.items) {
             double *acc = slabs.data() + it.slab_off;
             for (uint32_t pi = it.part_begin; pi < it.part_end; pi++) {
@@ -1438,7 +1435,6 @@ void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double
                         acc[(size_t)(P.tr0 + r) * it.cols + P.tc0 + c] += s;
                     }
             }
-            (void)TN;
         }
     }
     // two-stage path
