@@ -312,12 +312,14 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     // ... and the B fragments of the same chunk into bnxt
     auto fetch = [&](int kb, double *As) __attribute__((always_inline)) {
         fetch_dma(kb, As);
+        const char *bb = (const char *)(sB + (uint64_t)((uint32_t)kb * bstep));
+        const uint32_t b_s4 = tail ? 0u : bstep * 32u; // bytes per k-step (a partial chunk keeps its k offsets per lane)
 #pragma unroll
         for (int s = 0; s < KS; s++) {
-            const char *bb = (const char *)(sB + (uint64_t)((uint32_t)(kb + (tail ? 0 : 4 * s)) * bstep));
 #pragma unroll
             for (int q = 0; q < CF; q++)
                 bnxt[q][s] = *(const double *)(bb + vb[q][s]);
+            bb += b_s4;
         }
     };
     auto commit = [&]() __attribute__((always_inline)) {
