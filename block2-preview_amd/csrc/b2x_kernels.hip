@@ -482,13 +482,17 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     for (int q = 0; q < CF; q++) {
         const int col = wave * (CF * 16) + q * 16 + c;
         if (col < item.cols) {
+            // rows g, g + 4, g + 8, ...: a running pointer (one add per store, no 64-bit multiply); only the tile's last
+            // row fragment can be cut short (rows > 16 (TMF - 1) by construction), so only it tests the row
+            double *po = out + (int64_t)g * item.out_ld + col;
+            const int64_t step = (int64_t)4 * item.out_ld;
 #pragma unroll
             for (int f = 0; f < TMF; f++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    int row = f * 16 + 4 * r + g;
-                    if (row < item.rows)
-                        out[(int64_t)row * item.out_ld + col] = item.alpha * acc[f][q][r];
+                    if (f < TMF - 1 || f * 16 + 4 * r + g < item.rows)
+                        *po = item.alpha * acc[f][q][r];
+                    po += step;
                 }
         }
     }
