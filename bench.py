@@ -1,27 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py — H·psi throughput of the MI355X-native plan replay on the BASELINE workload.
+"""bench.py — H·psi throughput of the MI355X-native plan replay on the BASELINE workloads.
 
 One "step" = one H·psi (one replay of the GEMM-pair plan, sigma = H psi) — the unit the reference
 executes 5–90 times per site inside Davidson (src/core/iterative_matrix_functions.hpp:965-973).
 
-Workload (config.workload): the Cr2/SVP SU(2) mid-chain plan captured from the real reference at M=250
-(sweep 1, site 20; tests/golden/cr2_su2_m250_sw1_site20.struct.npz) with every sector dimension scaled
-x16 -> bond dimension M=4000, operator blocks / psi filled uniform [0,1) on the device.
-With N GPUs the operator terms of the plan are sharded sum-MPO style (every rank owns a subset of the
-left-operator blocks and only their data), each rank replays its share and the partial sigma is summed
-with ONE all-reduce (RCCL over xGMI) per step — strong scaling, as ParallelTensorFunctions::operator()
-does with MPI (src/core/parallel_tensor_functions.hpp:51-55).
+Workloads (--workload, config.workload in the output; all from plan structures the running reference recorded,
+operator blocks / psi filled uniform [0,1) on the device like Random::fill, src/core/utils.hpp:247-252):
+  cr2_m4000      (default; the configuration the BASELINE metric is quoted on) Cr2/SVP SU(2) mid-chain plan captured at
+                 M=250 (sweep 1, site 20) with every sector dimension x16 -> M=4000: 98 722 pairs, 20.7 TMAC, 73 GB
+  cr2_m2000      the same structure x8 -> M=2000 (BASELINE configs[2])
+  h10_m500       H10/STO-6G SZ at its TRUE M=500 mid-chain structure (configs[1]): 8 276 pairs, 0.48 GMAC
+  hubbard_m3000  1D Hubbard L=16 U/t=4 SZ at its TRUE M=3000 structure (configs[4]): 692 pairs, 54 GMAC
+With N GPUs the operator terms of the plan are sharded sum-MPO style (every rank owns a subset of the left-operator
+blocks and only their data), each rank replays its share and the partial sigma is summed with ONE all-reduce per step
+through the C ABI's RCCL communicator (b2x_allreduce_sum, over xGMI) — strong scaling, as
+ParallelTensorFunctions::operator() does with MPI (src/core/parallel_tensor_functions.hpp:51-55).
 
 `value` counts the ALGORITHMIC flops of the workload, 2 x the reference's nflop (2 * sum over pairs of
 m0 n0 k0 + m1 n1 k1, the reference's order of operations) — the BASELINE metric.  The plan compiler executes fewer: per
-pair it takes the cheaper association of op(Z).X.op(Y) and it computes a stage-0 product shared by several pairs once
-(`roofline.executed_over_algorithmic_macs`, 0.58 on this plan; same result up to rounding, nothing is cached across
-steps).  `roofline.achieved` / `frac` are the HARDWARE roofline — executed flops of the dominant kernel / its time —
-and `roofline.algorithmic_tflops` is the same kernel time in the reference's flop count (it may exceed the MFMA peak).
-`--keep-order 1` replays the reference's order pair by pair (executed == algorithmic).
+pair it takes the cheaper association of op(Z).X.op(Y), it computes a stage-0 product shared by several pairs once and
+sums products before a common factor (`roofline.executed_over_algorithmic_macs`; same result up to rounding, nothing is
+cached across steps).  `roofline.achieved` / `frac` are the HARDWARE roofline — flops the dominant kernel EXECUTES / its
+HIP-event time — and `roofline.algorithmic_tflops` is the same kernel time in the reference's flop count (it may exceed
+the MFMA peak, because that work is not executed).  `--keep-order 1` replays the reference's order pair by pair.
 
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around the dominant kernel;
-`cpu_baseline` replays a bounded sample of the same plan on the host cores, with the reference's own
+`cpu_baseline` replays a bounded, deterministic sample of the same plan on the host cores, with the reference's own
 BatchGEMMSeq executor (oracle/_ref/ref_replay, kind "reference") when that binary travelled with the repo,
 else with the repo's CPU restatement (kind "port").  Only that leg touches oracle/.
 """
@@ -39,6 +43,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor figure; measured ceiling in DESIGN.md)
+GOLD = os.path.join(ROOT, "tests", "golden")
+WORKLOADS = {
+    "cr2_m4000": ("cr2_su2_m250_sw1_site20.struct.npz", 16, 4000,
+                  "Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20) x16 -> M=4000"),
+    "cr2_m2000": ("cr2_su2_m250_sw1_site20.struct.npz", 8, 2000,
+                  "Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20) x8 -> M=2000"),
+    "cr2_m1000": ("cr2_su2_m250_sw1_site20.struct.npz", 4, 1000,
+                  "Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20) x4 -> M=1000"),
+    "cr2_m500": ("cr2_su2_m250_sw1_site20.struct.npz", 2, 500,
+                 "Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20) x2 -> M=500"),
+    "cr2_m250": ("cr2_su2_m250_sw1_site20.struct.npz", 1, 250,
+                 "Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20)"),
+    "h10_m500": ("h10_sz_m500_sw1_site4.struct.npz", 1, 500,
+                 "H10/STO-6G R=1.8 SZ mid-chain H.psi plan, reference capture at M=500 (sw1 site4)"),
+    "hubbard_m3000": ("hubbard_l16_u4_sz_m3000_sw0_site7.struct.npz", 1, 3000,
+                      "1D Hubbard L=16 U/t=4 SZ H.psi plan, reference capture at M=3000 (sw0 site7, fixed-M random MPS)"),
+}
 
 
 def parse():
@@ -46,9 +67,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scale", type=int, default=16, help="sector-dimension multiplier (16 -> M=4000)")
-    ap.add_argument("--struct", default=os.path.join(ROOT, "tests", "golden", "cr2_su2_m250_sw1_site20.struct.npz"))
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target host time of the cpu_baseline sample")
+    ap.add_argument("--workload", default="cr2_m4000", choices=sorted(WORKLOADS))
+    ap.add_argument("--scale", type=int, default=0, help="override the sector-dimension multiplier of the workload")
+    ap.add_argument("--struct", default="", help="override the plan structure file of the workload")
+    ap.add_argument("--cpu-gmac", type=float, default=0.0, help="MAC budget of the cpu_baseline sample (0 = auto)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed replays of the cpu_baseline sample (after one warm-up)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--tile-n", type=int, default=0)
     ap.add_argument("--item-macs", type=int, default=0)
@@ -59,8 +82,29 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(plan_pairs, psi_len, sigma_len, seconds, log):
-    """Replay a bounded random sample of the pairs on the host.  Returns the JSON object."""
+def sample_pairs(plan_pairs, budget_macs, max_op_bytes=12e9):
+    """Deterministic sample of the plan, stratified by pair size: the pairs are ordered by their MAC count and every
+    k-th one is taken (k chosen so that the sample holds about `budget_macs`), so every size class of the plan is
+    represented in proportion and two runs time exactly the same pairs.  Returns (indices, macs)."""
+    from block2_preview_amd import synth
+
+    pmac = (plan_pairs["m0"].astype(np.int64) * plan_pairs["n0"] * plan_pairs["k0"]
+            + plan_pairs["m1"].astype(np.int64) * plan_pairs["n1"] * plan_pairs["k1"])
+    order = np.argsort(-pmac, kind="stable")
+    total = int(pmac.sum())
+    stride = max(1, int(round(total / max(budget_macs, 1.0))))
+    while True:
+        sel = np.sort(order[stride // 2::stride])
+        if len(sel) == 0:
+            sel = order[:1]
+        _, alen = synth.compact_arena(plan_pairs[sel])
+        if alen * 8 <= max_op_bytes or len(sel) <= 1:
+            return sel, int(pmac[sel].sum())
+        stride *= 2  # keep the host copy of the sample's operator blocks under the cap
+
+
+def cpu_baseline(plan_pairs, psi_len, sigma_len, budget_macs, reps, log):
+    """Replay a bounded deterministic sample of the pairs on the host.  Returns the JSON object."""
     from block2_preview_amd import synth
     from block2_preview_amd.planfile import PlanFile, write_plan
 
@@ -74,23 +118,11 @@ def cpu_baseline(plan_pairs, psi_len, sigma_len, seconds, log):
         for f in os.listdir("/opt/conda/lib"):
             if f.startswith("libmkl_") and not os.path.exists(os.path.join(libdir, f)):
                 os.symlink(os.path.join("/opt/conda/lib", f), os.path.join(libdir, f))
-    rng = np.random.default_rng(20240)
-    order = rng.permutation(len(plan_pairs))
-    pmac = (plan_pairs["m0"].astype(np.int64) * plan_pairs["n0"] * plan_pairs["k0"]
-            + plan_pairs["m1"].astype(np.int64) * plan_pairs["n1"] * plan_pairs["k1"])
-    cum = np.cumsum(pmac[order])
-
-    def run(target_macs, reps=1):
-        n = int(np.searchsorted(cum, target_macs)) + 1
-        n = min(n, len(order))
-        sel = np.sort(order[:n])
-        pairs, alen = synth.compact_arena(plan_pairs[sel])
-        while alen * 8 > 12e9 and n > 1:  # keep the host operator sample under 12 GB
-            n //= 2
-            sel = np.sort(order[:n])
-            pairs, alen = synth.compact_arena(plan_pairs[sel])
-        macs = int(pmac[sel].sum())
-        if use_ref:
+    sel, macs = sample_pairs(plan_pairs, budget_macs)
+    pairs, alen = synth.compact_arena(plan_pairs[sel])
+    secs = None
+    if use_ref:
+        try:
             pf = PlanFile()
             pf.pairs, pf.psi_len, pf.sigma_len, pf.arena_len = pairs, psi_len, sigma_len, alen
             pf.max_work = int((pairs["m0"].astype(np.int64) * pairs["n0"]).max())
@@ -98,44 +130,50 @@ def cpu_baseline(plan_pairs, psi_len, sigma_len, seconds, log):
                 fn = os.path.join(td, "sample.plan")
                 write_plan(fn, pf)
                 env = dict(os.environ, MKL_THREADING_LAYER="GNU", OMP_NUM_THREADS=str(cores))
-                out = subprocess.run([ref_bin, fn, "threads=%d" % cores, "reps=%d" % reps], env=env,
+                out = subprocess.run([ref_bin, fn, "threads=%d" % cores, "reps=%d" % (reps + 1)], env=env,
                                      capture_output=True, text=True, timeout=900)
-            line = [l for l in out.stdout.splitlines() if l.startswith("REPLAY")]
-            if out.returncode != 0 or not line:
+            secs = [float(l.split("sec=")[1]) for l in out.stdout.splitlines() if l.startswith("REP ")]
+            if out.returncode != 0 or len(secs) != reps + 1:
                 raise RuntimeError("ref_replay failed: %s %s" % (out.stdout[-300:], out.stderr[-300:]))
-            sec = float(line[0].split("sec_per_replay=")[1].split()[0])
-        else:
-            from oracle import oracle
+            secs = secs[1:]  # the first replay is the warm-up (thread start, first touches)
+        except Exception as e:  # fall back to the port if the reference binary cannot run here
+            log("cpu_baseline: %s; falling back to the CPU restatement" % e)
+            use_ref, secs = False, None
+    if secs is None:
+        from oracle import oracle
 
-            g = np.random.default_rng(1)
-            arena, psi, sig = g.random(alen), g.random(psi_len), np.zeros(sigma_len)
+        g = np.random.default_rng(1)
+        arena, psi, sig = g.random(alen), g.random(psi_len), np.zeros(sigma_len)
+        secs = []
+        for r in range(reps + 1):
             t0 = time.time()
-            for _ in range(reps):
-                oracle.replay(pairs, arena, psi, sig, 1.0, cores)
-            sec = (time.time() - t0) / reps
-        return macs, sec, n
-
-    reps = 1
-    try:
-        macs, sec, n = run(4e9)  # calibration sample
-        rate = macs / max(sec, 1e-6)
-        macs, sec, n = run(max(4e9, rate * seconds))  # as many pairs as fit the host-memory cap
-        reps = max(1, int(round(seconds / max(sec, 1e-3))))  # ... replayed until ~`seconds` of CPU work
-        if reps > 1:
-            macs, sec, n = run(macs, reps)
-    except Exception as e:  # fall back to the port if the reference binary cannot run here
-        log("cpu_baseline: %s; falling back to the CPU restatement" % e)
-        use_ref = False
-        macs, sec, n = run(2e9)
-        reps = 1
+            oracle.replay(pairs, arena, psi, sig, 1.0, cores)
+            secs.append(time.time() - t0)
+        secs = secs[1:]
+    med, best = float(np.median(secs)), float(min(secs))
     return {
-        "value": round(2.0 * macs / sec / 1e9, 3), "unit": "GFLOP/s", "cores": cores,
+        "value": round(2.0 * macs / med / 1e9, 3), "unit": "GFLOP/s", "cores": cores,
         "kind": "reference" if use_ref else "port",
-        "sample": "%d randomly chosen pairs of the same plan (%.1f GMAC per replay, %.2f s per replay, %d replays, "
-                  "%d threads, %s)" % (
-            n, macs / 1e9, sec, reps, cores,
+        "best": round(2.0 * macs / best / 1e9, 3),
+        "sample": "every k-th pair of the same plan ordered by size: %d pairs, %.2f GMAC, %.1f GB of operators; median of "
+                  "%d timed replays after one warm-up (%.2f s median, %.2f s best; `best` = rate of the fastest), %d "
+                  "threads, %s" % (
+            len(sel), macs / 1e9, alen * 8 / 1e9, reps, med, best, cores,
             "block2 BatchGEMMSeq Tasked + MKL dgemm" if use_ref else "oracle/hpsi_oracle.c OpenMP loops"),
     }
+
+
+def traffic_of(workload):
+    """HBM bytes per H.psi of this workload from the committed PMC passes (separate rocprofv3 --pmc runs, corrected as the
+    micro-architecture guide prescribes; profiles/README.md).  The counters cannot be read from inside a timed run, so the
+    figure is carried with its source."""
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tf):
+        return None, None
+    tj = json.load(open(tf)).get(workload)
+    if not tj:
+        return None, None
+    return tj["fetch_bytes_per_hpsi"] + tj["write_bytes_per_hpsi"], tj.get("source")
 
 
 def main():
@@ -149,28 +187,49 @@ def main():
         raise SystemExit("launch with --nproc-per-node equal to --gpus")
     log = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
     ndev = torch.cuda.device_count()
-    if local >= ndev:  # rehearsal of the N>1 path on a 1-GPU box (B2X_DIST_BACKEND=gloo): ranks share the card
+    shared_card = local >= ndev  # rehearsal of the N>1 path on a 1-GPU box: the ranks share the card
+    if shared_card:
         local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    backend = os.environ.get("B2X_DIST_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
-    if world > 1:
-        import torch.distributed as dist
-
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
     from block2_preview_amd import capi, synth
     from block2_preview_amd.planfile import read_struct_npz
 
     capi.device_init(local)
+    comm, comm_kind = None, "none"
+    if world > 1:
+        import torch.distributed as dist
+
+        # control plane (barrier, max of the rank times): gloo.  Data plane: the C ABI's RCCL communicator.
+        dist.init_process_group("gloo")
+        if not shared_card and os.environ.get("B2X_BENCH_COMM", "b2x") == "b2x":
+            id_file = os.path.join(tempfile.gettempdir(), "b2x_rccl_id_%s_%s" % (
+                os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "0")))
+            try:
+                comm = capi.Comm(rank, world, id_file=id_file)
+                comm_kind = "b2x_allreduce_sum (RCCL through the C ABI)"
+            except capi.B2XError as e:
+                log("b2x_comm_init failed (%s)" % e)
+            dist.barrier()
+            if rank == 0 and os.path.exists(id_file):
+                os.remove(id_file)
+            ok = torch.tensor([1 if comm is not None else 0])
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                raise SystemExit("the RCCL communicator of the C ABI could not be created on every rank")
+        else:
+            comm_kind = "gloo via host (rehearsal: ranks share one card, RCCL refuses that)"
     t0 = time.time()
-    base = read_struct_npz(args.struct)
-    full = synth.scale_plan(base, args.scale)
+    sfile, scale, M, wname = WORKLOADS[args.workload]
+    if args.scale:
+        M, scale = M // scale * args.scale, args.scale
+        wname = "%s, sector dimensions x%d -> M=%d" % (sfile, scale, M)
+    if args.struct:
+        sfile, wname = args.struct, "pair plan %s x%d" % (os.path.basename(args.struct), scale)
+    base = read_struct_npz(sfile if os.path.isabs(sfile) else os.path.join(GOLD, sfile))
+    full = synth.scale_plan(base, scale) if scale != 1 else base
     mine, arena_len = synth.compact_arena(synth.shard_pairs(full.pairs, rank, world))
-    M = 250 * args.scale
-    log("plan: %d pairs (%d on rank 0), %.2f TMAC, psi %d, operators %.1f GB on rank 0, M=%d" % (
+    log("plan: %d pairs (%d on rank 0), %.3f TMAC, psi %d, operators %.2f GB on rank 0, M=%d" % (
         len(full.pairs), len(mine), full.macs / 1e12, full.psi_len, arena_len * 8 / 1e9, M))
     # synthetic data generated on the device: uniform [0,1) like Random::fill (src/core/utils.hpp:247-252)
     g = torch.Generator(device=dev)
@@ -187,19 +246,26 @@ def main():
     plan = capi.Plan(arena, mine, full.psi_len, full.sigma_len, tile_n=args.tile_n, item_macs=args.item_macs,
                      scratch_mb=args.scratch_mb, two_stage=args.two_stage, tile_m=args.tile_m, keep_order=args.keep_order)
     st = plan.stats
-    log("compiled in %.1f s: %s" % (time.time() - t0, st))
+    compile_s = time.time() - t0
+    log("compiled in %.1f s: %s" % (compile_s, st))
     stream = torch.cuda.current_stream().cuda_stream
+    host_sigma = torch.empty(full.sigma_len, dtype=torch.float64, pin_memory=True) if world > 1 and comm is None else None
 
     def one_step():
         sigma_t.zero_()  # Davidson clears sigma before every op() (iterative_matrix_functions.hpp:972)
         plan.execute_device(psi_t.data_ptr(), sigma_t.data_ptr(), 1.0, stream)
-        if world > 1:
-            dist.all_reduce(sigma_t)  # RCCL sum over xGMI == comm->allreduce_sum(c.data, c.size())
+        if comm is not None:  # == comm->allreduce_sum(c.data, c.size()) of ParallelTensorFunctions::operator()
+            comm.allreduce_sum(sigma_t.data_ptr(), full.sigma_len, stream)
+        elif world > 1:
+            host_sigma.copy_(sigma_t)
+            dist.all_reduce(host_sigma)
+            sigma_t.copy_(host_sigma)
 
     def fence():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_step()
@@ -210,19 +276,14 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     checksum = float(sigma_t.sum().item())
     # roofline of the dominant kernel on this rank: HIP events on the launch stream
     k_ms, tot_ms = plan.time_kernel(psi_t.data_ptr(), sigma_t.data_ptr(), max(1, min(args.steps, 3)), stream)
     if rank == 0:
-        traffic = None  # HBM bytes per H.psi from the PMC passes (profiles/README.md), same workload only
-        tf = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tf) and world == 1 and args.struct.endswith("cr2_su2_m250_sw1_site20.struct.npz"):
-            tj = json.load(open(tf))
-            if tj.get("scale") == args.scale:
-                traffic = tj["fetch_bytes_per_hpsi"] + tj["write_bytes_per_hpsi"]
+        traffic, traffic_source = traffic_of(args.workload) if world == 1 and not args.scale and not args.struct else (None, None)
         flops_step = 2.0 * full.macs
         value = flops_step * args.steps / dt / 1e9
         alg = 2.0 * st["macs_alg_dominant"] / (k_ms * 1e-3) / 1e12  # reference flop count of the pairs in that kernel
@@ -232,30 +293,34 @@ def main():
             "value": round(value, 1), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20) x%d -> M=%d"
-                                    % (args.scale, M)) if args.struct.endswith("cr2_su2_m250_sw1_site20.struct.npz") else
-                                   ("pair plan %s x%d -> M=%d" % (os.path.basename(args.struct), args.scale, M)),
-                       "pairs": int(len(full.pairs)), "tmac_per_step": round(full.macs / 1e12, 3),
-                       "psi_len": int(full.psi_len), "operator_gb": round(full.arena_len * 8 / 1e9, 1),
-                       "parallelism": "sum-MPO x%d" % world},
+            "config": {"workload": wname, "name": args.workload, "M": M,
+                       "pairs": int(len(full.pairs)), "tmac_per_step": round(full.macs / 1e12, 4),
+                       "psi_len": int(full.psi_len), "operator_gb": round(full.arena_len * 8 / 1e9, 2),
+                       "parallelism": "sum-MPO x%d" % world, "allreduce": comm_kind,
+                       "plan_compile_s": round(compile_s, 2), "plan_device_gb": round(st["device_bytes"] / 1e9, 2)},
             # `achieved` / `frac` are the HARDWARE roofline: flops the dominant kernel executes / its HIP-event time.
             # The plan executes fewer MACs than the reference's order of operations counts, so the
             # same kernel time expressed in the reference's (algorithmic) flops is `algorithmic_tflops`, which is what
             # `value` counts and which may exceed the MFMA peak.
             "roofline": {"bound": "mfma", "achieved": round(exe, 3), "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(exe / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "frac": round(exe / FP64_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_tflops": round(alg, 3),
                          "executed_over_algorithmic_macs": round(st["macs_executed"] / max(1, st["macs"]), 3),
                          "launches_per_step": st["n_launches"],
                          "kernel": ("gg_kernel (two-stage grouped GEMM, all launches of one H.psi)"
                                     if st["macs_issued"] else "hpsi_wave class %d" % st["dominant_class"]),
-                         "kernel_ms": round(k_ms, 3),
-                         "useful_over_issued_mfma": round(st["macs_dominant"] / st["macs_issued"], 3) if st["macs_issued"] else None},
+                         "kernel_ms": round(k_ms, 3), "hpsi_ms": round(tot_ms, 3),
+                         "useful_over_issued_mfma": round(st["macs_dominant"] / st["macs_issued"], 3) if st["macs_issued"] else None,
+                         "atomic_fallback": st["fallback"]},
             "sigma_checksum": checksum,
         }
         if world == 1 and not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(full.pairs, full.psi_len, full.sigma_len, args.cpu_seconds, log)
+            # ~1 TMAC of the M=4000 plan (5 s per replay at 200 GMAC/s), never more than the whole plan
+            budget = args.cpu_gmac * 1e9 if args.cpu_gmac > 0 else min(float(full.macs), 1.0e12)
+            out["cpu_baseline"] = cpu_baseline(full.pairs, full.psi_len, full.sigma_len, budget, args.cpu_reps, log)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,6 +24,8 @@ DECLARED_SYMBOLS = [
     "b2x_gemm_plan_create", "b2x_outer_build",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
     "b2x_vec_multi_dot", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
+    "b2x_comm_init", "b2x_comm_unique_id", "b2x_comm_init_id", "b2x_comm_rank", "b2x_allreduce_sum", "b2x_broadcast",
+    "b2x_barrier", "b2x_comm_destroy",
 ]
 
 
@@ -31,7 +33,7 @@ class PlanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_pairs", "macs", "op_elems_unique", "psi_len", "sigma_len", "n_targets", "n_tiles", "n_items",
         "n_parts", "device_bytes", "macs_executed", "dominant_class", "macs_dominant",
-        "macs_alg_dominant", "n_launches", "macs_issued")]
+        "macs_alg_dominant", "n_launches", "macs_issued", "fallback", "n_staged")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -88,7 +90,7 @@ def device_sync():
 
 
 class DeviceBuffer:
-    """fp64 device vector from b2x_device_alloc (16-byte read slack included, see b2x_plan_execute)"""
+    """fp64 device vector from b2x_device_alloc (exactly n elements)"""
 
     def __init__(self, n, host=None):
         p = C.c_void_p()
@@ -243,38 +245,42 @@ def outer_build(arena, terms, vin, vout, on_device=False, in_len=None, out_len=N
                                 C.c_size_t(out_len), _ptr(vout), C.c_int(1 if on_device else 0), C.c_void_p(int(stream))))
 
 
-def debug_compile_and_emulate_outer(terms, arena, vin, vout):
-    """TEST HOOK: compile an outer-term list into cells / work units and evaluate it with host loops."""
-    terms = np.ascontiguousarray(terms, OUTER_TERM_DTYPE)
-    nw, ne = C.c_uint64(), C.c_uint64()
-    check(lib().b2x_debug_compile_and_emulate_outer(
-        C.c_size_t(len(terms)), _ptr(terms), C.c_size_t(vin.size), C.c_size_t(vout.size), C.c_uint64(arena.size),
-        _ptr(arena), _ptr(vin), _ptr(vout), C.byref(nw), C.byref(ne)))
-    return nw.value, ne.value
+class Comm:
+    """RCCL communicator of the sum-MPO path (ParallelCommunicator<S> of the reference: allreduce_sum / broadcast /
+    barrier on device-resident fp64 vectors).  One process per GPU; call device_init() first."""
 
+    def __init__(self, rank, size, id_file=None, id_bytes=None):
+        h = C.c_void_p()
+        if id_bytes is not None:
+            buf = C.create_string_buffer(bytes(id_bytes), 128)
+            check(lib().b2x_comm_init_id(C.byref(h), C.c_int(rank), C.c_int(size), buf))
+        else:
+            check(lib().b2x_comm_init(C.byref(h), C.c_int(rank), C.c_int(size),
+                                      None if id_file is None else os.fsencode(id_file)))
+        self._h, self.rank, self.size = h, rank, size
 
-def debug_compile_and_emulate_gemms(gemms, in_len, out_len, arena, vin, vout, scale=1.0, item_macs=0, keep_order=0):
-    """TEST HOOK: compile a single-GEMM list and evaluate the compiled work list with host loops."""
-    gemms = np.ascontiguousarray(gemms, GEMM_DTYPE)
-    opt = PlanOptions()
-    opt.item_macs, opt.keep_order = item_macs, keep_order
-    st = PlanStats()
-    check(lib().b2x_debug_compile_and_emulate_gemms(
-        C.c_size_t(len(gemms)), _ptr(gemms), C.c_size_t(in_len), C.c_size_t(out_len), C.c_uint64(arena.size),
-        _ptr(arena), _ptr(vin), _ptr(vout), C.c_double(scale), C.byref(opt), C.byref(st)))
-    return st.as_dict()
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        check(lib().b2x_comm_unique_id(buf))
+        return buf.raw
 
+    def allreduce_sum(self, dev_ptr, n, stream=0):
+        check(lib().b2x_allreduce_sum(self._h, C.c_void_p(int(dev_ptr)), C.c_size_t(n), C.c_void_p(int(stream))))
 
-def debug_compile_and_emulate(pairs, psi_len, sigma_len, arena, psi, sigma, scale=1.0, tile_n=0, item_macs=0,
-                              two_stage=0, scratch_mb=0, keep_order=0, presum=0):
-    """TEST HOOK (not part of include/b2x.h): compile a plan and evaluate the compiled work list with
-    host loops, so the plan compiler can be verified without a GPU.  Returns (stats, fallback)."""
-    pairs = np.ascontiguousarray(pairs, PAIR_DTYPE)
-    opt = PlanOptions()
-    opt.tile_n, opt.item_macs = tile_n, item_macs
-    opt.two_stage, opt.scratch_mb, opt.keep_order, opt.presum = two_stage, scratch_mb, keep_order, presum
-    st, fb = PlanStats(), C.c_int(0)
-    check(lib().b2x_debug_compile_and_emulate(
-        C.c_size_t(len(pairs)), _ptr(pairs), C.c_size_t(psi_len), C.c_size_t(sigma_len), C.c_uint64(arena.size),
-        _ptr(arena), _ptr(psi), _ptr(sigma), C.c_double(scale), C.byref(opt), C.byref(st), C.byref(fb)))
-    return st.as_dict(), bool(fb.value)
+    def broadcast(self, dev_ptr, n, root=0, stream=0):
+        check(lib().b2x_broadcast(self._h, C.c_void_p(int(dev_ptr)), C.c_size_t(n), C.c_int(root), C.c_void_p(int(stream))))
+
+    def barrier(self):
+        check(lib().b2x_barrier(self._h))
+
+    def close(self):
+        if self._h is not None:
+            lib().b2x_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

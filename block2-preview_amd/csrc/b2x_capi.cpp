@@ -6,6 +6,7 @@
 #include "b2x_plan.hpp"
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <string>
@@ -18,6 +19,7 @@ static int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+int b2x_set_error(int code, const std::string &msg) { return fail(code, msg); } // for b2x_comm.cpp
 #define HIPCHK(expr)                                                                                                   \
     do {                                                                                                               \
         hipError_t e_ = (expr);                                                                                        \
@@ -25,9 +27,22 @@ static int fail(int code, const std::string &msg) {
             return fail(B2X_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));                           \
     } while (0)
 
+static const uint64_t kSlackElems = 8; // zeroed elements behind every buffer this library allocates itself
+
+// B2X_DEBUG_POISON=1 (test knob): memory the kernels must never consume — the slack behind owned buffers, the whole W
+// scratch before its first use — is filled with NaN instead of zeros, so a stray read shows up in the result.
+static bool poison() {
+    const char *e = getenv("B2X_DEBUG_POISON");
+    return e != nullptr && e[0] == '1';
+}
+static hipError_t fill_tail(double *p, uint64_t n) { // n elements: zeros (or NaN under the test knob)
+    return hipMemset(p, poison() ? 0xFF : 0, n * sizeof(double));
+}
+
 struct b2x_arena {
     double *dev = nullptr;
     uint64_t len = 0;
+    uint64_t cap = 0; // elements that may be read: len, + the slack of an owned arena
     bool owned = false;
     std::vector<const double *> host_bases; // sorted
     std::vector<uint64_t> host_lens, offs;
@@ -54,6 +69,7 @@ struct b2x_plan {
     OWork *d_sum_work = nullptr;   // sum pass between the stages (distributive law), scratch -> scratch
     OEntry *d_sum_entries = nullptr;
     std::vector<SuperStep> steps;
+    std::vector<StageCopy> stage_in; // input-vector operands copied into the scratch at the start of every execute
     double *d_psi = nullptr, *d_sigma = nullptr; // staging for host-pointer execute
     size_t psi_len = 0, sigma_len = 0;
     int dominant_cls = 0;
@@ -140,9 +156,31 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
             rc = upload(&p->d_sum_entries, cp.sum_entries);
         p->steps = cp.steps;
         if (rc == B2X_OK && cp.scratch_elems) {
-            hipError_t e = hipMalloc((void **)&p->d_scratch, (cp.scratch_elems + 8) * sizeof(double));
+            hipError_t e = hipMalloc((void **)&p->d_scratch, (cp.scratch_elems + kSlackElems) * sizeof(double));
             if (e != hipSuccess)
                 rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(W scratch): ") + hipGetErrorString(e));
+            // the scratch only ever holds finite values: zeroed here, written by the kernels with products of the inputs
+            // (the padding element behind an odd-sized W slot is never written and stays zero)
+            if (rc == B2X_OK && (e = fill_tail(p->d_scratch, cp.scratch_elems + kSlackElems)) != hipSuccess)
+                rc = fail(B2X_ERR_DEVICE, std::string("hipMemset(W scratch): ") + hipGetErrorString(e));
+            if (rc == B2X_OK && poison()) // the padding elements are zero in production; keep them so under the knob
+                for (uint64_t pad : cp.scratch_pads)
+                    if ((e = hipMemset(p->d_scratch + pad, 0, sizeof(double))) != hipSuccess) {
+                        rc = fail(B2X_ERR_DEVICE, std::string("hipMemset(pad): ") + hipGetErrorString(e));
+                        break;
+                    }
+            for (const StageCopy &sc : cp.stage) { // staged operands: arena sources are copied now
+                if (rc != B2X_OK)
+                    break;
+                e = hipSuccess;
+                if (sc.src == 0)
+                    e = hipMemcpy(p->d_scratch + sc.dst_off, arena->dev + sc.src_off, sc.len * sizeof(double),
+                                  hipMemcpyDeviceToDevice);
+                if (e != hipSuccess)
+                    rc = fail(B2X_ERR_DEVICE, std::string("staging an operand: ") + hipGetErrorString(e));
+                if (sc.src == 1)
+                    p->stage_in.push_back(sc);
+            }
         }
         if (rc == B2X_OK && !cp.aux_work.empty()) { // operator pre-sums: formed once, into the persistent head of the scratch
             OWork *dw = nullptr;
@@ -215,7 +253,7 @@ int b2x_device_sync(void) {
     return B2X_OK;
 }
 int b2x_device_alloc(void **dptr, size_t bytes) {
-    HIPCHK(hipMalloc(dptr, bytes + 64)); // slack: the kernels fetch 16-byte granules
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 8));
     return B2X_OK;
 }
 int b2x_device_free(void *dptr) {
@@ -252,8 +290,10 @@ int b2x_arena_create(b2x_arena **out, size_t n_ranges, const double *const *host
         a->offs.push_back(tot);
         tot += lens[i];
     }
-    a->len = tot, a->owned = true;
-    hipError_t e = hipMalloc((void **)&a->dev, (tot + 8) * sizeof(double)); // +64 B: 16-byte DMA granules may straddle the end
+    a->len = tot, a->cap = tot + kSlackElems, a->owned = true;
+    hipError_t e = hipMalloc((void **)&a->dev, a->cap * sizeof(double));
+    if (e == hipSuccess)
+        e = fill_tail(a->dev + tot, kSlackElems);
     if (e != hipSuccess) {
         delete a;
         return fail(B2X_ERR_NOMEM, std::string("hipMalloc(arena): ") + hipGetErrorString(e));
@@ -274,7 +314,7 @@ int b2x_arena_adopt_device(b2x_arena **out, double *dev_base, size_t len) {
     if (!out || (!dev_base && len))
         return fail(B2X_ERR_INVALID, "b2x_arena_adopt_device: null argument");
     b2x_arena *a = new b2x_arena();
-    a->dev = dev_base, a->len = len, a->owned = false;
+    a->dev = dev_base, a->len = len, a->cap = len, a->owned = false; // exactly len elements are ever read
     *out = a;
     return B2X_OK;
 }
@@ -324,7 +364,7 @@ int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, cons
         return fail(B2X_ERR_DEVICE, "b2x_plan_create: no HIP device (the H.psi path has no CPU fallback)");
     CompiledPlan cp;
     std::string err;
-    int rc = compile_plan(n_pairs, pairs, psi_len, sigma_len, arena->len, opt, cp, err);
+    int rc = compile_plan(n_pairs, pairs, psi_len, sigma_len, arena->len, arena->cap, opt, cp, err);
     if (rc != B2X_OK)
         return fail(rc, "b2x_plan_create: " + err);
     return plan_upload(out, arena, cp, n_pairs, pairs, psi_len, sigma_len, opt);
@@ -339,7 +379,7 @@ int b2x_gemm_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_gemms,
         return fail(B2X_ERR_DEVICE, "b2x_gemm_plan_create: no HIP device (this path has no CPU fallback)");
     CompiledPlan cp;
     std::string err;
-    int rc = compile_gemm_list(n_gemms, gemms, in_len, out_len, arena->len, opt, cp, err);
+    int rc = compile_gemm_list(n_gemms, gemms, in_len, out_len, arena->len, arena->cap, opt, cp, err);
     if (rc != B2X_OK)
         return fail(rc, "b2x_gemm_plan_create: " + err);
     return plan_upload(out, arena, cp, 0, nullptr, in_len, out_len, nullptr);
@@ -353,6 +393,8 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
     for (int k = 0; k < kNumClasses; k++)
         HIPCHK(launch_main(k, p->d_parts[k], p->d_items[k], p->n_items[k], p->arena->dev, psi, p->d_slabs, st));
     HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma, scale, st));
+    for (const StageCopy &sc : p->stage_in) // (degenerate operands at the very end of the input vector; normally none)
+        HIPCHK(hipMemcpyAsync(p->d_scratch + sc.dst_off, psi + sc.src_off, sc.len * sizeof(double), hipMemcpyDeviceToDevice, st));
     for (const SuperStep &ss : p->steps) {
         HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st));
         if (ss.sum_end > ss.sum_begin)
@@ -371,7 +413,7 @@ int b2x_plan_execute(b2x_plan *p, const double *psi, double *sigma, double scale
     if (on_device)
         return run_plan(p, psi, sigma, scale, st);
     if (!p->d_psi)
-        HIPCHK(hipMalloc((void **)&p->d_psi, (p->psi_len + 8) * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&p->d_psi, (p->psi_len ? p->psi_len : 1) * sizeof(double)));
     if (!p->d_sigma)
         HIPCHK(hipMalloc((void **)&p->d_sigma, (p->sigma_len ? p->sigma_len : 1) * sizeof(double)));
     HIPCHK(hipMemcpyAsync(p->d_psi, psi, p->psi_len * sizeof(double), hipMemcpyHostToDevice, st));
@@ -620,74 +662,6 @@ int b2x_vec_lincomb(const double *const *vs, int nv, const double *coef, double 
     if (nv < 1 || nv > 64)
         return fail(B2X_ERR_INVALID, "b2x_vec_lincomb: need 1 <= nv <= 64");
     HIPCHK(launch_lincomb(vs, coef, nv, y, n, (hipStream_t)stream));
-    return B2X_OK;
-}
-
-// test hook: segmentation of diagonal terms only (no device)
-int b2x_debug_compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,
-                           uint64_t *n_comps) {
-    std::vector<DiagComp> comps;
-    std::vector<DiagTermD> dterms;
-    std::string err;
-    int rc = compile_diag(n_terms, terms, diag_len, arena_len, comps, dterms, err);
-    if (rc != B2X_OK)
-        return fail(rc, err);
-    if (n_comps)
-        *n_comps = comps.size();
-    return B2X_OK;
-}
-
-// ---------------------------------------------------------------------------------- test hook
-// Compiles a plan and evaluates the compiled work list with plain host loops.  Exists so the
-// non-GPU test-suite can verify the PLAN COMPILER (segmentation into tiles/parts/items) against
-// the oracle; it is not declared in include/b2x.h and nothing in the product calls it.
-int b2x_debug_compile_and_emulate(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len,
-                                  uint64_t arena_len, const double *arena, const double *psi, double *sigma,
-                                  double scale, const b2x_plan_options *opt, b2x_plan_stats *stats, int *fallback) {
-    CompiledPlan cp;
-    std::string err;
-    int rc = compile_plan(n_pairs, pairs, psi_len, sigma_len, arena_len, opt, cp, err);
-    if (rc != B2X_OK)
-        return fail(rc, err);
-    if (stats)
-        *stats = cp.stats;
-    if (fallback)
-        *fallback = cp.fallback ? 1 : 0;
-    if (!cp.fallback && arena && psi && sigma)
-        emulate_plan_host(cp, arena, psi, sigma, scale);
-    return B2X_OK;
-}
-
-int b2x_debug_compile_and_emulate_gemms(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size_t out_len,
-                                        uint64_t arena_len, const double *arena, const double *in, double *out,
-                                        double scale, const b2x_plan_options *opt, b2x_plan_stats *stats) {
-    CompiledPlan cp;
-    std::string err;
-    int rc = compile_gemm_list(n_gemms, gemms, in_len, out_len, arena_len, opt, cp, err);
-    if (rc != B2X_OK)
-        return fail(rc, err);
-    if (stats)
-        *stats = cp.stats;
-    if (arena && in && out)
-        emulate_plan_host(cp, arena, in, out, scale);
-    return B2X_OK;
-}
-
-int b2x_debug_compile_and_emulate_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, size_t out_len,
-                                        uint64_t arena_len, const double *arena, const double *in, double *out,
-                                        uint64_t *n_work, uint64_t *n_entries) {
-    std::vector<OWork> work;
-    std::vector<OEntry> entries;
-    std::string err;
-    int rc = compile_outer(n_terms, terms, in_len, out_len, arena_len, work, entries, err);
-    if (rc != B2X_OK)
-        return fail(rc, err);
-    if (n_work)
-        *n_work = work.size();
-    if (n_entries)
-        *n_entries = entries.size();
-    if (arena && out)
-        emulate_outer_host(work, entries, arena, in, out);
     return B2X_OK;
 }
 

@@ -246,6 +246,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     uint32_t va[NI];     // per DMA instruction: byte offset of this lane's granule from the chunk's A base
     uint32_t vb[CF][KS]; // byte offset of this lane's B element from the k-step's B base
     uint32_t astep = 1, bstep = 1;
+    uint32_t a_adj = 0;  // bytes the chunk's A base is moved back by (odd k tail, see lane_offsets)
     uint32_t bmask = 0;  // B mask of the chunk that is fetched next (columns; k tail)
     bool tail = false;   // the offsets in va / vb are those of the partial last chunk
     double salpha = 1.0; // SB (single-GEMM lists): per-segment factor, folded into the B fragments
@@ -253,8 +254,20 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
 
     // per-lane offsets of the chunk at k offset kb of segment S: unclamped for a full chunk (valid for every full chunk
     // of the segment), clamped to the last k for the partial one
+    // No load ever leaves its operand: a 16-byte granule that would straddle the end of a row (odd k tail) or of the
+    // tile's rows (odd row count) is fetched one element EARLIER instead, and the consumer follows it:
+    //  * k-contiguous A, partial chunk with an odd number n of valid k: the last granule holds k = n-2, n-1 in its slots
+    //    n-1, n; the B side then masks slot n-1 and feeds k = n-1 through slot n (one common shift for the segment);
+    //  * row-contiguous (k-major) A with an odd number of rows: the last granule holds rows mr-2, mr-1 in the MFMA rows
+    //    mr-1, mr, and the tile store takes the last row from MFMA row mr (k-contiguous segments clamp rows >= mr to
+    //    row mr-1 anyway, so both layouts agree on MFMA row mr).
+    // Left over: K == 1 (k-contiguous) and mr == 1 (row-contiguous) still touch one element behind the operand; the
+    // plan compiler stages such an operand in plan-owned memory when that element would lie outside its buffer.
     auto lane_offsets = [&](const GSeg &S, int kb, bool part) __attribute__((always_inline)) {
-        const uint32_t akmax = (uint32_t)(S.K - 1 - kb) * astep; // relative to the chunk base
+        const int n = S.K - kb; // valid k of this chunk (part: n < KC)
+        const bool odd = part && !s_kmaj && (n & 1) && (n > 1 || kb > 0);
+        a_adj = odd ? 8u : 0u; // odd tail: the chunk's A base moves one element back, the offsets one forward
+        const uint32_t akmax = (uint32_t)(n - 1) * astep; // relative to the chunk base
 #pragma unroll
         for (int j = 0; j < NI; j++) {
             // granule G of the LDS image is written by lane `lane` of DMA instruction (wave, j)
@@ -262,17 +275,24 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
             uint32_t ro, ko;
             if (s_kmaj) { // fragment-major image [f][k][16 rows]: granule = rows (f*16 + 2p, +1) of one k
                 const int f = G / (KC * 8), kl = (G % (KC * 8)) >> 3, p2 = G & 7;
-                ro = (uint32_t)min(f * 16 + 2 * p2, S.mr - 1);
+                const int r2 = f * 16 + 2 * p2;
+                ro = (uint32_t)(r2 + 1 < S.mr ? r2 : max(S.mr - 2, 0));
                 ko = (uint32_t)kl * astep;
+                ko = part ? min(ko, akmax) : ko;
             } else { // image [TM rows][KC k]; granule slot gs of a row holds k = 2*(gs ^ swz(row)), +1
                 const int row = G / (KC / 2), gs = G % (KC / 2);
                 const int swz = KC == 16 ? ((row >> 1) & 7) : (row & 15);
                 ro = (uint32_t)min(row, S.mr - 1) * (uint32_t)S.a_sr;
-                ko = (uint32_t)(2 * (gs ^ swz));
+                const int k2 = 2 * (gs ^ swz);
+                if (!part)
+                    ko = (uint32_t)k2;
+                else if (odd) // (+1: relative to the base moved back by a_adj)
+                    ko = (uint32_t)((k2 < n - 1 ? k2 : n - 2) + 1);
+                else
+                    ko = (uint32_t)min(k2, max(n - 2, 0));
             }
-            va[j] = (ro + (part ? min(ko, akmax) : ko)) * 8u;
+            va[j] = (ro + ko) * 8u;
         }
-        const uint32_t bkmax = (uint32_t)(S.K - 1 - kb) * bstep;
         bmask = 0;
 #pragma unroll
         for (int q = 0; q < CF; q++) {
@@ -282,8 +302,11 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 // full chunk: the k-step's 4 s rows are in the scalar base; partial chunk: base = chunk start
-                vb[q][s] = (co + (part ? min((uint32_t)(4 * s + g) * bstep, bkmax) : (uint32_t)g * bstep)) * 8u;
-                bmask |= (uint32_t)(in && (!part || kb + 4 * s + g < S.K)) << (q * KS + s);
+                const int js = 4 * s + g; // k slot of this lane
+                const int krel = (odd && js == n) ? n - 1 : min(js, n - 1);
+                const bool kin = odd ? (js < n - 1 || js == n) : js < n;
+                vb[q][s] = (co + (part ? (uint32_t)krel * bstep : (uint32_t)g * bstep)) * 8u;
+                bmask |= (uint32_t)(in && (!part || kin)) << (q * KS + s);
             }
         }
         tail = part;
@@ -301,7 +324,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     };
     // the A half of a fetch: this wave's share of the LDS-DMA of the chunk at k offset kb into LDS buffer `As`
     auto fetch_dma = [&](int kb, double *As) __attribute__((always_inline)) {
-        const char *ba = (const char *)(sA + (uint64_t)((uint32_t)kb * astep));
+        const char *ba = (const char *)(sA + (uint64_t)((uint32_t)kb * astep)) - a_adj;
 #pragma unroll
         for (int j = 0; j < NI; j++)
             if (NG % NT == 0 || (wave * NI + j) * 64 < NG) // whole DMA instruction inside the image
@@ -478,6 +501,8 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     }
     // ---- store the tile ----
     double *out = (item.out_kind ? scratch : slabs) + item.out_off;
+    // an odd number of rows: the last row was accumulated in MFMA row `rows` (see lane_offsets), MFMA row rows-1 is void
+    const int r_lim = (item.rows & 1) ? item.rows - 1 : item.rows, r_alt = (item.rows & 1) ? item.rows : -1;
 #pragma unroll
     for (int q = 0; q < CF; q++) {
         const int col = wave * (CF * 16) + q * 16 + c;
@@ -490,8 +515,15 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
             for (int f = 0; f < TMF; f++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    if (f < TMF - 1 || f * 16 + 4 * r + g < item.rows)
+                    if (f < TMF - 1)
                         *po = item.alpha * acc[f][q][r];
+                    else {
+                        const int i = f * 16 + 4 * r + g;
+                        if (i < r_lim)
+                            *po = item.alpha * acc[f][q][r];
+                        else if (i == r_alt)
+                            *(po - item.out_ld) = item.alpha * acc[f][q][r];
+                    }
                     po += step;
                 }
         }

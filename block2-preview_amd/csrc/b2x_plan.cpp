@@ -133,10 +133,43 @@ std::vector<Component> build_components(std::vector<Window> &win, bool &fallback
     return comps;
 }
 
+// Every slot of the scratch (a W product, a sum, a staged operand) is followed by at least one padding element that no
+// kernel ever writes (it stays zero from the allocation on): the one element a degenerate K = 1 / one-row operand
+// fetch may touch behind the slot.  Returns the slot's footprint (even: slots stay 16-byte aligned).
+inline uint64_t slot_elems(CompiledPlan &out, uint64_t off, uint64_t size) {
+    out.scratch_pads.push_back(off + size);
+    return (size + 2) & ~(uint64_t)1;
+}
+
+// see StageCopy (b2x_plan.hpp): called once all segments of a plan exist
+void stage_residual_reads(CompiledPlan &out, uint64_t arena_cap, uint64_t in_cap) {
+    std::map<std::pair<uint64_t, uint64_t>, uint64_t> done[2]; // (offset, extent) -> scratch offset, per source
+    for (GSeg &g : out.gsegs) {
+        if (g.a_src > 1)
+            continue; // the scratch is plan-owned: slack behind it, always finite (zeroed when allocated)
+        const bool kmaj = g.a_sk != 1;
+        if (!(kmaj ? g.mr == 1 : g.K == 1))
+            continue;
+        const uint64_t ext = (uint64_t)(g.mr - 1) * (uint64_t)g.a_sr + (uint64_t)(g.K - 1) * (uint64_t)g.a_sk + 1;
+        if (g.a_off + ext + 1 <= (g.a_src == 0 ? arena_cap : in_cap))
+            continue;
+        auto key = std::make_pair(g.a_off, ext);
+        auto it = done[g.a_src].find(key);
+        if (it == done[g.a_src].end()) {
+            const uint64_t dst = out.scratch_elems;
+            out.scratch_elems += slot_elems(out, dst, ext);
+            out.stage.push_back(StageCopy{(uint32_t)g.a_src, g.a_off, dst, ext});
+            it = done[g.a_src].emplace(key, dst).first;
+        }
+        g.a_src = 2, g.a_off = it->second;
+    }
+    out.stats.n_staged = out.stage.size();
+}
+
 } // namespace
 
 int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len, uint64_t arena_len,
-                 const b2x_plan_options *opt, CompiledPlan &out, std::string &err) {
+                 uint64_t arena_cap, const b2x_plan_options *opt, CompiledPlan &out, std::string &err) {
     out = CompiledPlan();
     b2x_plan_stats &st = out.stats;
     st.n_pairs = n_pairs, st.psi_len = psi_len, st.sigma_len = sigma_len;
@@ -190,6 +223,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         win[i] = Window{pairs[i].v_off, pairs[i].m1, pairs[i].n1, pairs[i].ldc1, (uint32_t)i};
     std::vector<Component> comps = build_components(win, out.fallback, out.fallback_reason);
     st.n_targets = comps.size();
+    st.fallback = out.fallback;
     if (out.fallback)
         return B2X_OK;
     // ---- tiles, parts, items -----------------------------------------------------------------
@@ -542,7 +576,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         if (gsz > 1 && dim * (double)(gsz - 1) / (double)(gsz + 1) > 64.0) {
                             const int srows = fl ? p0.m1 : p0.k1, scols = fl ? p0.k0 : p0.n0;
                             const uint64_t s_off = used + sum_extra;
-                            sum_extra += (((uint64_t)srows * scols) + 1) & ~(uint64_t)1;
+                            sum_extra += slot_elems(out, s_off, (uint64_t)srows * scols);
                             const uint32_t eb = (uint32_t)out.sum_entries.size();
                             for (size_t x = a; x < b; x++) {
                                 const b2x_pair &px = ep[win[cur[mk[x].q].wi].pair];
@@ -773,7 +807,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     const b2x_pair p0 = ep[lead];
                     const int srows = fl ? p0.k0 : p0.m1, scols = fl ? p0.n0 : p0.k1; // op(Y) is k0 x n0, op(Z) is m1 x k1
                     const uint64_t s_off = aux_len;
-                    aux_len += (((uint64_t)srows * scols) + 1) & ~(uint64_t)1;
+                    aux_len += slot_elems(out, s_off, (uint64_t)srows * scols);
                     const uint32_t eb = (uint32_t)out.aux_entries.size();
                     for (size_t x = a2; x < b2; x++) {
                         const b2x_pair &px = ep[win[cand[pk[x].q].wi].pair];
@@ -829,9 +863,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 cur.push_back(PW{cd.c, cd.wi, last_off, cd.flip, false});
                 continue;
             }
-            uint64_t wsz = ((cd.flip ? (uint64_t)p.m1 * p.k0 : (uint64_t)p.k1 * p.n0) + 1) & ~(uint64_t)1;
-            if (used - aux_len + wsz > budget && !cur.empty()) // (the budget bounds the per-step part of the scratch)
+            const uint64_t wexact = cd.flip ? (uint64_t)p.m1 * p.k0 : (uint64_t)p.k1 * p.n0;
+            if (used - aux_len + wexact + 2 > budget && !cur.empty()) // (the budget bounds the per-step part of the scratch)
                 flush();
+            const uint64_t wsz = slot_elems(out, used, wexact);
             cur.push_back(PW{cd.c, cd.wi, used, cd.flip, true});
             last_off = used;
             used += wsz;
@@ -858,13 +893,14 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         for (const SuperStep &ss : out.steps)
             st.n_launches += (ss.s0_v[kGGVariants] > ss.s0_v[0]) + (ss.s1_v[kGGVariants] > ss.s1_v[0]);
     }
+    stage_residual_reads(out, std::max(arena_cap, arena_len), psi_len);
     st.device_bytes = (out.scratch_elems + out.gslab_elems) * 8 + out.gsegs.size() * sizeof(GSeg) +
                       out.gitems.size() * sizeof(GItem) + out.gtiles.size() * sizeof(DTile) + slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
     return B2X_OK;
 }
 
 int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size_t out_len, uint64_t arena_len,
-                      const b2x_plan_options *opt, CompiledPlan &out, std::string &err) {
+                      uint64_t arena_cap, const b2x_plan_options *opt, CompiledPlan &out, std::string &err) {
     out = CompiledPlan();
     out.seg_scaled = true;
     b2x_plan_stats &st = out.stats;
@@ -1010,7 +1046,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
                         continue;
                     }
                     s_off = s_used;
-                    s_used += (((uint64_t)srows * scols) + 1) & ~(uint64_t)1;
+                    s_used += slot_elems(out, s_off, (uint64_t)srows * scols);
                     const uint32_t eb = (uint32_t)out.sum_entries.size();
                     for (uint32_t i : mem) {
                         OEntry e{};
@@ -1184,6 +1220,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     }
     out.steps.push_back(ss);
     out.gslab_elems = slab;
+    stage_residual_reads(out, std::max(arena_cap, arena_len), in_len);
     st.n_tiles = out.gtiles.size(), st.n_items = out.gitems.size(), st.n_parts = out.gsegs.size();
     st.macs_executed = gg_macs;
     st.dominant_class = kNumClasses, st.macs_dominant = gg_macs, st.macs_alg_dominant = st.macs, st.n_launches = 1;
@@ -1309,31 +1346,6 @@ int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, si
     return B2X_OK;
 }
 
-void emulate_outer_host(const std::vector<OWork> &work, const std::vector<OEntry> &entries, const double *arena,
-                        const double *in, double *out) {
-    static const double one = 1.0;
-    for (const OWork &w : work) {
-        const uint32_t nseg = (uint32_t)ceil_div(w.cols, kOuterTileCols);
-        for (uint32_t tile = w.t_begin; tile < w.t_end; tile++) {
-            const int r0 = (int)(tile / nseg) * w.rpt, c0 = (int)(tile % nseg) * kOuterTileCols;
-            for (int r = r0; r < std::min(w.rows, r0 + w.rpt); r++)
-                for (int c = c0; c < std::min(w.cols, c0 + kOuterTileCols); c++) {
-                    double sum = 0.0;
-                    for (uint32_t k = w.entry_begin; k < w.entry_end; k++) {
-                        const OEntry &t = entries[k];
-                        const double a = t.a_src == 2 ? one : (t.a_src ? in : arena)[t.a_off + (uint64_t)r * t.a_rs + (uint64_t)c * t.a_cs];
-                        const double b = t.b_src == 2 ? one : (t.b_src ? in : arena)[t.b_off + (uint64_t)r * t.b_rs + (uint64_t)c * t.b_cs];
-                        sum += t.alpha * a * b;
-                    }
-                    if (w.ld < 0)
-                        out[w.out_off + (uint64_t)r * (uint64_t)(-w.ld) + c] = sum;
-                    else
-                        out[w.out_off + (uint64_t)r * w.ld + c] += sum;
-                }
-        }
-    }
-}
-
 int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,
                  std::vector<DiagComp> &comps, std::vector<DiagTermD> &dterms, std::string &err) {
     comps.clear(), dterms.clear();
@@ -1408,88 +1420,6 @@ int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, ui
         i = j;
     }
     return B2X_OK;
-}
-
-void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double *psi, double *sigma, double scale) {
-    std::vector<double> slabs(cp.slab_elems, 0.0);
-    for (int k = 0; k < kNumClasses; k++) {
-        const ClassWork &cw = cp.cls[k];
-        for (const DItem &it : cw.items) {
-            double *acc = slabs.data() + it.slab_off;
-            for (uint32_t pi = it.part_begin; pi < it.part_end; pi++) {
-                const DPart &P = cw.parts[pi];
-                std::vector<double> w((size_t)P.k1 * P.nc);
-                for (int r = 0; r < P.k1; r++)
-                    for (int c = 0; c < P.nc; c++) {
-                        double s = 0;
-                        for (int k2 = 0; k2 < P.k0; k2++)
-                            s += psi[P.x_off + (uint64_t)r * P.ldx + k2] *
-                                 arena[P.y_off + (uint64_t)k2 * P.sky + (uint64_t)c * P.scy];
-                        w[(size_t)r * P.nc + c] = s * P.alpha;
-                    }
-                for (int r = 0; r < P.mr; r++)
-                    for (int c = 0; c < P.nc; c++) {
-                        double s = 0;
-                        for (int k2 = 0; k2 < P.k1; k2++)
-                            s += arena[P.z_off + (uint64_t)r * P.srz + (uint64_t)k2 * P.skz] * w[(size_t)k2 * P.nc + c];
-                        acc[(size_t)(P.tr0 + r) * it.cols + P.tc0 + c] += s;
-                    }
-            }
-        }
-    }
-    // two-stage path
-    std::vector<double> scratch(cp.scratch_elems, 0.0), gslabs(cp.gslab_elems, 0.0);
-    if (!cp.aux_work.empty()) // operator pre-sums (done once at plan creation on the device)
-        emulate_outer_host(cp.aux_work, cp.aux_entries, arena, scratch.data(), scratch.data());
-    auto run_item = [&](const GItem &it) {
-        std::vector<double> acc((size_t)it.rows * it.cols, 0.0);
-        for (uint32_t si = it.seg_begin; si < it.seg_end; si++) {
-            const GSeg &g = cp.gsegs[si];
-            const double *A = g.a_src == 0 ? arena : (g.a_src == 1 ? psi : scratch.data());
-            const double *B = g.b_src == 0 ? arena : (g.b_src == 1 ? psi : scratch.data());
-            for (int r = 0; r < g.mr; r++)
-                for (int c = 0; c < g.nc; c++) {
-                    double s = 0;
-                    for (int k = 0; k < g.K; k++)
-                        s += A[g.a_off + (uint64_t)r * g.a_sr + (uint64_t)k * g.a_sk] *
-                             B[g.b_off + (uint64_t)k * g.b_sk + (uint64_t)c * g.b_sc];
-                    acc[(size_t)r * it.cols + g.tc0 + c] += g.alpha * s;
-                }
-        }
-        double *o = (it.out_kind ? scratch.data() : gslabs.data()) + it.out_off;
-        for (int r = 0; r < it.rows; r++)
-            for (int c = 0; c < it.cols; c++)
-                o[(size_t)r * it.out_ld + c] = it.alpha * acc[(size_t)r * it.cols + c];
-    };
-    for (const SuperStep &ss : cp.steps) {
-        for (uint32_t i = ss.s0_v[0]; i < ss.s0_v[kGGVariants]; i++)
-            run_item(cp.gitems[i]);
-        if (ss.sum_end > ss.sum_begin) { // S = sum_i alpha_i W_i (scratch -> scratch)
-            std::vector<OWork> wk(cp.sum_work.begin() + ss.sum_begin, cp.sum_work.begin() + ss.sum_end);
-            std::vector<double> src = scratch;
-            emulate_outer_host(wk, cp.sum_entries, arena, src.data(), scratch.data());
-        }
-        for (uint32_t i = ss.s1_v[0]; i < ss.s1_v[kGGVariants]; i++)
-            run_item(cp.gitems[i]);
-        for (uint32_t ti = ss.tile_begin; ti < ss.tile_end; ti++) {
-            const DTile &t = cp.gtiles[ti];
-            for (int r = 0; r < t.rows; r++)
-                for (int c = 0; c < t.cols; c++) {
-                    double s = 0;
-                    for (int i = 0; i < t.n_items; i++)
-                        s += gslabs[t.slab_off + (uint64_t)i * t.rows * t.cols + (uint64_t)r * t.cols + c];
-                    sigma[t.sigma_off + (uint64_t)r * t.ld + c] += scale * s;
-                }
-        }
-    }
-    for (const DTile &t : cp.tiles)
-        for (int r = 0; r < t.rows; r++)
-            for (int c = 0; c < t.cols; c++) {
-                double s = 0;
-                for (int i = 0; i < t.n_items; i++)
-                    s += slabs[t.slab_off + (uint64_t)i * t.rows * t.cols + (uint64_t)r * t.cols + c];
-                sigma[t.sigma_off + (uint64_t)r * t.ld + c] += scale * s;
-            }
 }
 
 } // namespace b2x

@@ -96,6 +96,18 @@ struct OWork {
 static_assert(sizeof(OWork) == 40, "OWork layout");
 static const int kOuterTileCols = 64;
 
+// The grouped-GEMM kernel fetches A operands as 16-byte granules.  It never reads outside an operand except in two
+// degenerate shapes (gg_body::lane_offsets): a k-contiguous operand with K == 1 and a row-contiguous one with a single
+// row touch ONE element behind the operand.  Where that element would lie outside the source buffer (an operand that
+// ends exactly at the end of an adopted arena or of the caller's psi), the operand is copied into plan-owned memory that
+// has a zero behind it, and the segment reads the copy.
+struct StageCopy {
+    uint32_t src;     // 0 = operator arena, 1 = input vector
+    uint64_t src_off; // element offset in the source buffer
+    uint64_t dst_off; // element offset in the scratch
+    uint64_t len;
+};
+
 // stage 0 of a batch of pairs -> W scratch; stage 1 consumes it; reduce adds the slabs into psi'.
 // All items of a stage share one launch (range [s?_v[0], s?_v[kGGVariants])); every workgroup picks the kernel body
 // for its tile height (rows rounded up to 16).
@@ -151,6 +163,10 @@ struct CompiledPlan {
     // operator pre-sums, built once when the plan is created (arena -> the first elements of the scratch)
     std::vector<OWork> aux_work;
     std::vector<OEntry> aux_entries;
+    // operands staged in the tail of the scratch (stage_residual_reads): arena sources are copied once when the plan is
+    // uploaded, input-vector sources at the start of every execute
+    std::vector<StageCopy> stage;
+    std::vector<uint64_t> scratch_pads; // the padding element behind every scratch slot (only the B2X_DEBUG_POISON knob needs the list)
 };
 
 // ---- diagonal build ----------------------------------------------------------------------------------------
@@ -167,24 +183,19 @@ struct DiagComp {
 };
 int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, size_t out_len, uint64_t arena_len,
                   std::vector<OWork> &work, std::vector<OEntry> &entries, std::string &err);
-// host evaluation of the compiled work list (TEST HOOK)
-void emulate_outer_host(const std::vector<OWork> &work, const std::vector<OEntry> &entries, const double *arena,
-                        const double *in, double *out);
 
 // groups the terms by output sector (overlapping windows), keeping plan order inside a sector
 int compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,
                  std::vector<DiagComp> &comps, std::vector<DiagTermD> &dterms, std::string &err);
 
 // returns 0 / B2X_ERR_INVALID (err filled)
+// arena_cap: elements of the arena buffer that may be READ (>= arena_len: an owned arena has slack behind it)
 int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len, uint64_t arena_len,
-                 const b2x_plan_options *opt, CompiledPlan &out, std::string &err);
+                 uint64_t arena_cap, const b2x_plan_options *opt, CompiledPlan &out, std::string &err);
 
 // single-GEMM list (b2x_gemm records) -> one super-step of stage-1-shaped items (no stage 0, no W scratch)
 int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size_t out_len, uint64_t arena_len,
-                      const b2x_plan_options *opt, CompiledPlan &out, std::string &err);
+                      uint64_t arena_cap, const b2x_plan_options *opt, CompiledPlan &out, std::string &err);
 
-// Host emulation of exactly what the device kernels compute from a CompiledPlan (plain loops, no
-// MFMA).  TEST HOOK for the plan compiler only — never reachable from b2x_plan_execute.
-void emulate_plan_host(const CompiledPlan &cp, const double *arena, const double *psi, double *sigma, double scale);
 
 } // namespace b2x

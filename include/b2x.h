@@ -82,6 +82,10 @@ typedef struct b2x_plan_stats {
     uint64_t macs_alg_dominant; /* reference-count MACs (the pairs' m0 n0 k0 + m1 n1 k1) of the work in the dominant kernel */
     uint64_t n_launches;      /* launches of the dominant kernel per execute */
     uint64_t macs_issued;     /* MFMA issue slots x 1024 of the two-stage path incl. tile padding (0 if unused) */
+    uint64_t fallback;        /* 1: the output windows could not be segmented, the plan runs on the per-pair atomic kernel
+                                 (not bitwise reproducible); 0 for every plan the reference's DMRG records */
+    uint64_t n_staged;        /* operands copied into plan-owned memory because a 16-byte fetch would otherwise touch an
+                                 element behind the caller's buffer (degenerate K = 1 / one-row operands at a buffer end) */
 } b2x_plan_stats;
 
 /* tuning knobs; pass NULL for defaults */
@@ -105,7 +109,7 @@ const char *b2x_version(void);
 int b2x_device_count(int *n);
 int b2x_device_init(int ordinal);                 /* hipSetDevice; fails if no gfx950 device */
 int b2x_device_sync(void);
-int b2x_device_alloc(void **dptr, size_t bytes);  /* hipMalloc (+64 bytes of slack, see b2x_plan_execute) */
+int b2x_device_alloc(void **dptr, size_t bytes);  /* hipMalloc of exactly `bytes` */
 int b2x_device_free(void *dptr);
 int b2x_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int b2x_memcpy_d2h(void *dst, const void *src, size_t bytes);
@@ -115,7 +119,8 @@ int b2x_memcpy_d2h(void *dst, const void *src, size_t bytes);
  * plan points into (src/core/operator_tensor.hpp:47; immutable for one EffectiveHamiltonian). */
 int b2x_arena_create(b2x_arena **out, size_t n_ranges, const double *const *host_bases,
                      const size_t *lens);               /* concatenates + uploads */
-int b2x_arena_adopt_device(b2x_arena **out, double *dev_base, size_t len); /* no copy, not owned */
+int b2x_arena_adopt_device(b2x_arena **out, double *dev_base, size_t len); /* no copy, not owned; exactly len
+                                                                              elements are ever read (no slack needed) */
 int b2x_arena_resolve(const b2x_arena *a, const double *host_ptr, uint64_t *off);
 int b2x_arena_len(const b2x_arena *a, uint64_t *len);
 int b2x_arena_device_ptr(const b2x_arena *a, double **dev_base);
@@ -126,8 +131,8 @@ int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, cons
                     size_t psi_len, size_t sigma_len, const b2x_plan_options *opt);
 /* sigma += scale * H * psi.  on_device != 0: psi/sigma are device pointers (no copies);
  * stream: hipStream_t (NULL = default stream).  Asynchronous when on_device != 0.
- * A device psi must be readable for 16 bytes past psi_len (the kernels fetch 16-byte granules; the extra
- * element is never used): buffers from b2x_device_alloc and any allocator with >= 16-byte slack qualify. */
+ * Exactly psi_len elements of psi, sigma_len of sigma and the arena's len elements are accessed: buffers need no
+ * slack (the kernels fetch 16-byte granules, but never one that leaves its operand; see b2x_plan_stats.n_staged). */
 int b2x_plan_execute(b2x_plan *p, const double *psi, double *sigma, double scale, int on_device,
                      void *stream);
 int b2x_plan_get_stats(const b2x_plan *p, b2x_plan_stats *st);
@@ -201,6 +206,27 @@ typedef struct b2x_outer_term {
 /* out += sum of terms.  on_device != 0: in / out are device pointers.  Deterministic (no atomics). */
 int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term *terms, const double *in, size_t in_len,
                     size_t out_len, double *out, int on_device, void *stream);
+
+/* sum-MPO communicator ------------------------------------------------------------------------------------------
+ * Replaces: ParallelCommunicator<S>::allreduce_sum(double*, size_t), broadcast(double*, size_t, int), barrier()
+ * (src/core/parallel_rule.hpp:55, 74, 128; MPI bodies src/core/parallel_mpi.hpp:300-309, 133-141, 125-132) for the
+ * device-resident vectors of this path: ParallelTensorFunctions::operator() sums the partial H.psi of the ranks
+ * (src/core/parallel_tensor_functions.hpp:51-55), the diagonal is summed once per site (:853), Davidson broadcasts from
+ * the root.  Transport: RCCL (over xGMI inside a node); one process per GPU; the communicator binds to the device that
+ * is current when it is created (call b2x_device_init first).  Rendezvous without MPI: rank 0 writes the 128-byte RCCL
+ * id to `id_file` (a path every rank can read — any local directory on one node; the caller removes it afterwards), the
+ * other ranks wait for it (120 s).  A launcher with its own broadcast uses b2x_comm_unique_id + b2x_comm_init_id.
+ * Collectives are asynchronous and ordered on `stream` (hipStream_t, NULL = default stream): they run on the
+ * communicator's own stream once the work queued on `stream` so far is done, and `stream` resumes after them. */
+typedef struct b2x_comm b2x_comm;
+int b2x_comm_init(b2x_comm **out, int rank, int size, const char *id_file);
+int b2x_comm_unique_id(void *id128);                                   /* rank 0: a fresh 128-byte id */
+int b2x_comm_init_id(b2x_comm **out, int rank, int size, const void *id128);
+int b2x_comm_rank(const b2x_comm *c, int *rank, int *size);
+int b2x_allreduce_sum(b2x_comm *c, double *dev, size_t n, void *stream); /* in place, SUM over ranks */
+int b2x_broadcast(b2x_comm *c, double *dev, size_t n, int root, void *stream);
+int b2x_barrier(b2x_comm *c);                                          /* returns when every rank has arrived */
+int b2x_comm_destroy(b2x_comm *c);
 
 /* device-resident vector algebra for Davidson (all pointers are device pointers) ------------ */
 int b2x_vec_dot(const double *x, const double *y, size_t n, double *host_result, void *stream);

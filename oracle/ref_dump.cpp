@@ -32,12 +32,19 @@
  *                                            SparseMatrix::save_data(file, true) (src/core/sparse_matrix.hpp:957-971) next to
  *                                            its content as named arrays (on-disk format fixture)
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
+ *   prefactors=1                             (with para=) also write ParallelRuleSimple::index_prefactor of every (i,j), (i,j,k,l)
+ *   para=i|ij                                sum-MPO parallel rule (ParallelRuleSimple I / IJ); under mpirun with the
+ *                                            _HAS_MPI build every rank writes <outprefix>.r<rank>of<size>.*
+ *   stop_after=<sweep>:<site>                leave the run right after the captures of that site (large-M structure runs)
  */
 #include "block2_core.hpp"
 #include "block2_dmrg.hpp"
 #include "planfile.h"
+#include <execinfo.h>
 #include <map>
 #include <set>
+#include <signal.h>
+#include <unistd.h>
 
 using namespace block2;
 using namespace std;
@@ -620,6 +627,7 @@ template <typename S> struct Dumper : CallbackKernel {
     bool start_forward = true; // DMRG::forward is only written when solve() returns: sweep isw runs forward iff
                                // (isw even) == start_forward (src/dmrg/sweep_algorithm.hpp:3076-3101)
     mutable vector<string> log;
+    pair<int, int> stop_after = make_pair(-1, -1);
     mutable map<pair<int, int>, string> pending; // file awaiting psi_out / energy
     void compute(const string &name, int iprint) const override {
         if (dmrg == nullptr)
@@ -632,6 +640,16 @@ template <typename S> struct Dumper : CallbackKernel {
                 capture(isw, site, wd);
             if (spec.eham.count(key))
                 capture_eham(isw, site);
+            if (stop_after == key) { // structure captures at large M: the rest of the sweep is not needed
+                ofstream lf((spec.prefix + ".log").c_str());
+                for (auto &l : log)
+                    lf << l << endl;
+                lf << "STOPPED_AFTER " << isw << " " << site << endl;
+                lf.close();
+                cout << "STOPPED_AFTER " << isw << " " << site << endl;
+                cout.flush();
+                _exit(0); // the run is abandoned on purpose (no teardown)
+            }
         } else if (name == "DMRG::sweep::iter.eff_ham.end") {
             bool wd = spec.pnoise.count(key), st = spec.pnoise_struct.count(key), en = spec.enoise.count(key);
             if (wd || st || en)
@@ -1013,10 +1031,53 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     S vacuum(0);
     int norb = fcidump->n_sites();
     S target(fcidump->n_elec(), fcidump->twos(), PointGroup::swap_pg(pg)(fcidump->isym()));
+    // para=i|ij: the sum-MPO parallel rule: integrals masked by ParallelRuleSimple::index_prefactor
+    // (src/dmrg/parallel_simple.hpp:56-99; wrapped as in unit_test/mpi/test_sum_mpo_n2_sto3g.cpp:183-190 and
+    // src/main.cpp:233-238), every rank builds the MPO of ITS integrals, ParallelMPO around it.  Built with -D_HAS_MPI and started under mpirun every rank runs its own H_r; the
+    // captured plan is the rank's, sigma_ref is what ParallelTensorFunctions::operator() returned: the ALL-REDUCED H psi.
+    shared_ptr<ParallelRuleSimple<S, FL>> para_rule;
+    string rank_tag;
+    if (kv.count("para")) {
+#ifdef _HAS_MPI
+        shared_ptr<ParallelCommunicator<S>> comm = make_shared<MPICommunicator<S>>();
+#else
+        shared_ptr<ParallelCommunicator<S>> comm = make_shared<ParallelCommunicator<S>>(1, 0, 0);
+#endif
+        para_rule = make_shared<ParallelRuleSimple<S, FL>>(
+            kv["para"] == "ij" ? ParallelSimpleTypes::IJ : ParallelSimpleTypes::I, comm);
+        fcidump = make_shared<ParallelFCIDUMP<S, FL>>(fcidump, para_rule);
+        if (comm->size > 1)
+            rank_tag = ".r" + Parsing::to_string(comm->rank) + "of" + Parsing::to_string(comm->size);
+        if (kv.count("prefactors")) { // this rank's share of every integral index (what the partition rule must reproduce)
+            ArrayFile af(prefix + rank_tag + ".prefactors");
+            vector<double> pij((size_t)norb * norb), pijkl((size_t)norb * norb * norb * norb);
+            for (int i = 0; i < norb; i++)
+                for (int j = 0; j < norb; j++) {
+                    pij[(size_t)i * norb + j] = para_rule->index_prefactor(i, j);
+                    for (int k = 0; k < norb; k++)
+                        for (int l = 0; l < norb; l++)
+                            pijkl[(((size_t)i * norb + j) * norb + k) * norb + l] = para_rule->index_prefactor(i, j, k, l);
+                }
+            af.u64("meta", vector<uint64_t>{(uint64_t)norb, (uint64_t)comm->rank, (uint64_t)comm->size,
+                                            (uint64_t)(kv["para"] == "ij" ? 3 : 1)});
+            af.f64("ij", pij), af.f64("ijkl", pijkl);
+        }
+    }
     auto hamil = make_shared<HamiltonianQC<S, FL>>(vacuum, norb, orbsym, fcidump);
-    shared_ptr<MPO<S, FL>> mpo = make_shared<MPOQC<S, FL>>(hamil, QCTypes::Conventional);
-    mpo = make_shared<SimplifiedMPO<S, FL>>(mpo, make_shared<RuleQC<S, FL>>(), true, true,
-                                             OpNamesSet({OpNames::R, OpNames::RD}));
+    shared_ptr<MPO<S, FL>> mpo;
+    if (para_rule != nullptr) {
+        // as src/main.cpp:312-320, 463-470 ("simple_parallel"): the ordinary QC MPO of the masked integrals, the
+        // NC -> CN switch moved to trans_center = norb / (1 + 1/sqrt(size)), ParallelMPO around it
+        int trans_center = (int)(norb / (1 + 1.0 / sqrt((double)para_rule->comm->size)));
+        QCTypes qct = trans_center >= norb - 2 ? QCTypes::NC : QCTypes::Conventional;
+        mpo = make_shared<MPOQC<S, FL>>(hamil, qct, "HQC", trans_center);
+        mpo = make_shared<SimplifiedMPO<S, FL>>(mpo, make_shared<RuleQC<S, FL>>(), true);
+        mpo = make_shared<ParallelMPO<S, FL>>(mpo, para_rule);
+    } else {
+        mpo = make_shared<MPOQC<S, FL>>(hamil, QCTypes::Conventional);
+        mpo = make_shared<SimplifiedMPO<S, FL>>(mpo, make_shared<RuleQC<S, FL>>(), true, true,
+                                                 OpNamesSet({OpNames::R, OpNames::RD}));
+    }
     Random::rand_seed(kv.count("seed") ? (unsigned)Parsing::to_int(kv["seed"]) : 1234u);
     auto mps_info = make_shared<MPSInfo<S>>(norb, vacuum, target, hamil->basis);
     if (kv.count("occ")) {
@@ -1051,7 +1112,8 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     mps_info->deallocate_mutable();
     auto me = make_shared<MovingEnvironment<S, FL, FL>>(mpo, mps, mps, "DMRG");
     me->init_environments(false);
-    me->delayed_contraction = OpNamesSet::normal_ops();
+    if (para_rule == nullptr) // (the reference's sum-MPO test keeps the default: no delayed contraction)
+        me->delayed_contraction = OpNamesSet::normal_ops();
     me->cached_contraction = true;
     vector<ubond_t> bdims = {(ubond_t)M};
     vector<double> noises = {1E-8, 1E-9, 0.0};
@@ -1067,8 +1129,10 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     dmrg->davidson_soft_max_iter = kv.count("dav_iter") ? Parsing::to_int(kv["dav_iter"]) : 4000;
     auto dumper = make_shared<Dumper<S>>();
     dumper->dmrg = dmrg.get();
-    dumper->spec.prefix = prefix;
+    dumper->spec.prefix = prefix + rank_tag;
     dumper->start_forward = mps->center == 0;
+    if (kv.count("stop_after"))
+        dumper->stop_after = *parse_pairs(kv["stop_after"]).begin();
     if (kv.count("dump"))
         dumper->spec.with_data = parse_pairs(kv["dump"]);
     if (kv.count("struct"))
@@ -1121,21 +1185,42 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
             cerr << "TENSOR " << fn << " n=" << t->info->n << " len=" << t->total_memory << endl;
             mps->unload_tensor(i);
         }
-    ofstream lf((prefix + ".log").c_str());
+    ofstream lf((prefix + rank_tag + ".log").c_str());
     lf.precision(15);
     for (auto &l : dumper->log)
         lf << l << endl;
     lf << "FINAL_ENERGY " << energy << endl;
     lf << "TOTAL_TIME " << tt << endl;
     for (size_t i = 0; i < dmrg->energies.size(); i++)
-        lf << "SWEEP_ENERGY " << i << " " << dmrg->energies[i][0] << " T " << dmrg->sweep_time[i] << endl;
+        lf << "SWEEP_ENERGY " << i << " " << dmrg->energies[i][0] << endl; // (DMRG::sweep_time is only filled by the
+                                                                             // parallel-site sweep: indexing it here was
+                                                                             // the crash at the end of every earlier run)
     cout.precision(15);
     cout << "FINAL_ENERGY " << energy << " T = " << tt << endl;
+    // teardown in the order the reference's own tests use (unit_test/test_dmrg_n2_sto3g.cpp:121-122, 142, 236-237, 39-43):
+    // persistent stack memory is released explicitly, newest first, before the frame goes away
+    mps_info->deallocate();
     me->remove_partition_files();
+    mpo->deallocate();
+    hamil->deallocate();
+    fcidump->deallocate();
+    dumper->dmrg = nullptr;
+    frame_<double>()->activate(0);
+    frame_<double>() = nullptr;
     return 0;
 }
 
+static void on_fault(int sig) { // a crashing generator must not pass for a finished one: say where, exit non-zero
+    void *bt[64];
+    int n = backtrace(bt, 64);
+    const char msg[] = "ref_dump: fatal signal, backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(bt, n, 2);
+    _exit(128 + sig);
+}
+
 int main(int argc, char **argv) {
+    signal(SIGSEGV, on_fault), signal(SIGABRT, on_fault);
     if (argc < 6) {
         cerr << "usage: ref_dump <fcidump|hubbard:L:t:U> <su2|sz> <M> <n_sweeps> <outprefix> [key=value ...]" << endl;
         return 2;

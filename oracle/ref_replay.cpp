@@ -10,7 +10,7 @@
  * thread-private psi', tree reduction.
  *
  * usage: ref_replay <plan> [out=<sigma.bin>] [reps=<n>] [threads=<n>] [scale=<x>] [seed=<n>]
- * prints: REPLAY pairs=<n> macs=<n> threads=<t> reps=<r> sec_per_replay=<s> gmacs=<x>
+ * prints: REP <i> sec=<s> per replay, then REPLAY pairs=<n> macs=<n> threads=<t> reps=<r> sec_per_replay=<s> gmacs=<x>
  */
 #include "block2_core.hpp"
 #include "planfile.h"
@@ -71,14 +71,18 @@ int main(int argc, char **argv) {
     vector<double> sigma(pf.sigma_len, 0.0);
     Timer t;
     t.get_time();
+    double total = 0;
+    cout.precision(9);
     for (int r = 0; r < reps; r++) {
         if (r == reps - 1)
             fill(sigma.begin(), sigma.end(), 0.0);
         (*seq)(GMatrix<double>(pf.psi, (MKL_INT)pf.psi_len, 1), GMatrix<double>(sigma.data(), (MKL_INT)pf.sigma_len, 1),
                scale);
+        const double dt = t.get_time();
+        total += dt;
+        cout << "REP " << r << " sec=" << dt << endl; // (the first replay also pays MKL's thread start and first touches)
     }
-    double tt = t.get_time() / reps;
-    cout.precision(9);
+    double tt = total / reps;
     cout << "REPLAY pairs=" << pf.n_pairs << " macs=" << macs << " threads=" << nth << " reps=" << reps
          << " sec_per_replay=" << tt << " gmacs=" << (double)macs / tt * 1e-9 << endl;
     if (kv.count("out")) {

@@ -14,8 +14,7 @@ $R $D/N2.STO3G.FCIDUMP sz 60 6 ./n2sz dump=1:6,2:4 iprint=0
 $R $D/H10.STO6G.R1.8.FCIDUMP sz 50 6 ./h10szm50 dump=0:6,1:5,2:4 iprint=0
 # Cr2/SVP structure-only plans (pair descriptors, no operator data), converted to .struct.npz by
 #   python -c "from block2_preview_amd.planfile import *; write_struct_npz(out, read_plan(in))"
-# (the run ends with a harmless crash in the reference's teardown after all files are written)
-$R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2m250 struct=1:5,1:10,1:20,1:30,0:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
+$R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2m250 struct=1:5,1:10,1:20,1:30,0:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1
 # effective-Hamiltonian level fixtures (operator infos, operator tensors incl. delayed ones, term list of H_eff,
 # the reference's ConnectionInfo, psi, diag, sigma_ref): input AND expected output of the symbolic -> numeric layer
 $R $D/N2.STO3G.FCIDUMP sz 40 4 ./e_n2sz eham=1:5 iprint=0
@@ -29,14 +28,14 @@ $R $D/N2.STO3G.FCIDUMP su2 60 3 ./p_n2su2 pnoise=0:3,1:5 enoise=0:3,1:5 iprint=0
 $R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./p_h10sz pnoise=0:5,1:4 enoise=1:4 iprint=0
 # Cr2/SVP M=250 noise lists, structure only; converted to .pnoise_struct.npz by
 #   python -c "from block2_preview_amd.planfile import *; write_gemm_struct_npz(out, read_gemm_list(in))"
-$R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2m250 pnoise_struct=0:20,1:20,1:10 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
+$R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2m250 pnoise_struct=0:20,1:20,1:10 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1
 # environment-rotation fixtures: the GEMM pairs the reference's own tensor_rotate records (Auto mode)
 # for TensorFunctions::left_rotate / right_rotate, the enlarged operators, the MPS tensor and the rotated operators the
 # reference computed (.plan), plus the same step at the symbolic level (.erot: operator infos, MPS tensor infos)
 # (rotation and blocking fixtures come from ONE run per molecule, see the blocking entry below, so that the enlarged
 #  operators the blocking step produces are exactly the rotation's input: tests chain them on the device)
 # Cr2/SVP M=250 rotation structures -> *.rotstruct.npz (write_struct_npz)
-$R $D/CR2.SVP.FCIDUMP su2 250 2 ./rcr2 rot_struct=0:20,1:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
+$R $D/CR2.SVP.FCIDUMP su2 250 2 ./rcr2 rot_struct=0:20,1:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1
 # blocking fixtures: the element-wise block-product terms re-grouped from the k = 1 GEMM groups the
 # reference's own TensorFunctions::tensor_product records (Auto mode) for left_contract / right_contract, the block and
 # site operators and the enlarged operators the reference computed
@@ -45,8 +44,18 @@ $R $D/N2.STO3G.FCIDUMP su2 60 3 ./x_n2su2 blk=0:4,1:4 eblk=0:4,1:4 rot=0:4,1:4 e
 $R $D/H10.STO6G.R1.8.FCIDUMP sz 30 3 ./x_h10sz blk=0:5 eblk=0:5 rot=0:5,1:4 erot=0:5 iprint=0
 for f in x_*; do case $f in *blk*) n=blk_${f#x_};; *rot*) n=rot_${f#x_};; *) n=lcr_${f#x_};; esac; mv $f $n; done
 # Cr2/SVP M=250 blocking structures -> *.blkstruct.npz (planfile.write_outer_struct_npz)
-$R $D/CR2.SVP.FCIDUMP su2 250 2 ./bcr2 blk_struct=0:20,1:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1 || true
+$R $D/CR2.SVP.FCIDUMP su2 250 2 ./bcr2 blk_struct=0:20,1:20 occ=$D/CR2.SVP.OCC noise=1e-5,1e-5 iprint=1
 # on-disk format fixtures: MPS tensors written by the reference's own SparseMatrix::save_data(file, true)
 # next to their content as named arrays (.arr)
 $R $D/N2.STO3G.FCIDUMP su2 60 2 ./disk_n2su2 tensor_file=3,6 iprint=0
 $R $D/H10.STO6G.R1.8.FCIDUMP sz 30 2 ./disk_h10sz tensor_file=4 iprint=0
+# BASELINE configs[4]: 1D Hubbard L=16 U/t=4 (HubbardFCIDUMP, src/core/hubbard.hpp:30-82), SZ: golden plans with data at
+# M=100 and the TRUE M=3000 structure of the two-site step 7-8 in sweep 0 (fixed-M random MPS; the run stops after the
+# capture) -> hubbard_l16_u4_sz_m3000_sw0_site7.struct.npz
+$R hubbard:16:1:4 sz 100 4 ./hubu4m100 dump=1:7,2:3 iprint=0 noise=1e-5,1e-5,1e-6,0
+$R hubbard:16:1:4 sz 3000 1 ./hub3000 struct=0:7 stop_after=0:7 dav_iter=2 iprint=2
+# BASELINE configs[1] at its true size: H10/STO-6G SZ M=500 mid-chain structure -> h10_sz_m500_sw1_site4.struct.npz
+$R $D/H10.STO6G.R1.8.FCIDUMP sz 500 2 ./h10m500 struct=1:4 stop_after=1:4 iprint=1
+# sum-MPO partition: the reference on 2 MPI ranks with ParallelRuleSimple(IJ) (make -C oracle _ref/ref_dump_mpi):
+# every rank's own plan + operators, psi, and sigma_ref = the ALL-REDUCED H psi; *.prefactors = index_prefactor tables
+/opt/conda/bin/mpirun -n 2 ../../oracle/_ref/ref_dump_mpi $D/N2.STO3G.FCIDUMP su2 200 6 ./n2su2_ij para=ij prefactors=1 dump=1:5,2:4 nthreads=4 iprint=0

@@ -1,0 +1,95 @@
+// b2x_testhooks.cpp — TEST-ONLY library (tests/native/libb2x_testhooks.so): evaluates the work lists the plan compiler
+// produces with plain host loops, so that the non-GPU test-suite can verify the PLAN COMPILER (segmentation into tiles /
+// parts / items, the algebraic rewrites) against the oracle.  It links the host-only compiler source
+// (block2-preview_amd/csrc/b2x_plan.cpp) and nothing of the device path; it is NOT part of libb2x.so and nothing in the
+// product loads it.
+#include "b2x_emulate.hpp"
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace b2x;
+using b2x_test::emulate_outer_host;
+using b2x_test::emulate_plan_host;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+extern "C" {
+
+const char *b2x_test_last_error(void) { return g_err.c_str(); }
+
+// test hook: segmentation of diagonal terms only (no device)
+int b2x_debug_compile_diag(size_t n_terms, const b2x_diag_term *terms, size_t diag_len, uint64_t arena_len,
+                           uint64_t *n_comps) {
+    std::vector<DiagComp> comps;
+    std::vector<DiagTermD> dterms;
+    std::string err;
+    int rc = compile_diag(n_terms, terms, diag_len, arena_len, comps, dterms, err);
+    if (rc != B2X_OK)
+        return fail(rc, err);
+    if (n_comps)
+        *n_comps = comps.size();
+    return B2X_OK;
+}
+
+// ---------------------------------------------------------------------------------- test hook
+// Compiles a plan and evaluates the compiled work list with plain host loops.  Exists so the
+// non-GPU test-suite can verify the PLAN COMPILER (segmentation into tiles/parts/items) against
+// the oracle; it is not declared in include/b2x.h and nothing in the product calls it.
+int b2x_debug_compile_and_emulate(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t sigma_len,
+                                  uint64_t arena_len, const double *arena, const double *psi, double *sigma,
+                                  double scale, const b2x_plan_options *opt, b2x_plan_stats *stats, int *fallback) {
+    CompiledPlan cp;
+    std::string err;
+    int rc = compile_plan(n_pairs, pairs, psi_len, sigma_len, arena_len, arena_len, opt, cp, err);
+    if (rc != B2X_OK)
+        return fail(rc, err);
+    if (stats)
+        *stats = cp.stats;
+    if (fallback)
+        *fallback = cp.fallback ? 1 : 0;
+    if (!cp.fallback && arena && psi && sigma)
+        emulate_plan_host(cp, arena, psi, sigma, scale);
+    return B2X_OK;
+}
+
+int b2x_debug_compile_and_emulate_gemms(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size_t out_len,
+                                        uint64_t arena_len, const double *arena, const double *in, double *out,
+                                        double scale, const b2x_plan_options *opt, b2x_plan_stats *stats) {
+    CompiledPlan cp;
+    std::string err;
+    int rc = compile_gemm_list(n_gemms, gemms, in_len, out_len, arena_len, arena_len, opt, cp, err);
+    if (rc != B2X_OK)
+        return fail(rc, err);
+    if (stats)
+        *stats = cp.stats;
+    if (arena && in && out)
+        emulate_plan_host(cp, arena, in, out, scale);
+    return B2X_OK;
+}
+
+int b2x_debug_compile_and_emulate_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, size_t out_len,
+                                        uint64_t arena_len, const double *arena, const double *in, double *out,
+                                        uint64_t *n_work, uint64_t *n_entries) {
+    std::vector<OWork> work;
+    std::vector<OEntry> entries;
+    std::string err;
+    int rc = compile_outer(n_terms, terms, in_len, out_len, arena_len, work, entries, err);
+    if (rc != B2X_OK)
+        return fail(rc, err);
+    if (n_work)
+        *n_work = work.size();
+    if (n_entries)
+        *n_entries = entries.size();
+    if (arena && out)
+        emulate_outer_host(work, entries, arena, in, out);
+    return B2X_OK;
+}
+
+
+} // extern "C"

@@ -1,7 +1,9 @@
 """bench.py keeps its contract: one JSON line with the metric, the roofline object and the cpu_baseline object
-(run at M=250 so that it takes seconds; the default run is the M=4000 workload)."""
+(run on the M=250 workload so that it takes seconds; the default run is the M=4000 workload), and its N > 1 path —
+per-rank shard of the plan, compact arena, all-reduce of the device sigma — gives the one-rank result."""
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -12,13 +14,18 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def test_bench_json_contract(gpu):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "1", "--steps", "2", "--warmup", "1",
-                          "--cpu-seconds", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+def _json_line(out):
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout
-    j = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_json_contract(gpu):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cr2_m250", "--steps", "2",
+                          "--warmup", "1", "--cpu-gmac", "2", "--cpu-reps", "2"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    j = _json_line(out)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in j, k
@@ -28,6 +35,26 @@ def test_bench_json_contract(gpu):
     r = j["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
     assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    assert r["traffic"] is None  # the PMC figure belongs to the M=4000 workload only
+    assert r["atomic_fallback"] == 0
+    assert (r["traffic"] is None) == (r["traffic_source"] is None)  # a PMC figure always names the profile it comes from
     c = j["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["unit"] == "GFLOP/s" and c["sample"]
+    assert c["best"] >= c["value"]
+
+
+def test_bench_two_ranks_share_one_card(gpu):
+    """the N = 2 path of bench.py (torch.distributed.run, as the driver launches it; the two ranks share card 0, so the
+    all-reduce goes through the host): sharded sigma summed over the ranks == the one-rank sigma"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    common = ["--workload", "cr2_m250", "--steps", "1", "--warmup", "1", "--no-cpu"]
+    one = _json_line(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common, capture_output=True,
+                                    text=True, timeout=600, cwd=ROOT))
+    two = _json_line(subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                                     "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                     os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common, capture_output=True,
+                                    text=True, timeout=900, cwd=ROOT))
+    assert two["n_gpus"] == 2 and "x2" in two["config"]["parallelism"]
+    assert abs(two["sigma_checksum"] - one["sigma_checksum"]) <= 1e-10 * abs(one["sigma_checksum"])

@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 
+import hooks
 from conftest import GOLDEN
 from block2_preview_amd.planfile import OUTER_TERM_DTYPE, read_arrays
 
@@ -109,7 +110,7 @@ def test_compiled_outer_matches_reference(built, fn):
 
     t, d = load_blk(fn)
     out = np.zeros(int(d["lens"][3]))
-    nw, ne = capi.debug_compile_and_emulate_outer(t, d["arena"], d["in"], out)
+    nw, ne = hooks.debug_compile_and_emulate_outer(t, d["arena"], d["in"], out)
     assert nw > 0 and ne >= len(t)
     assert np.abs(out - d["out_ref"]).max() <= 1e-12 * max(1.0, np.abs(d["out_ref"]).max())
 
@@ -125,7 +126,7 @@ def test_compiled_outer_random(built, seed):
     ref = rng.standard_normal(out_len)
     out = ref.copy()
     numpy_outer(t, arena, vin, ref)
-    capi.debug_compile_and_emulate_outer(t, arena, vin, out)
+    hooks.debug_compile_and_emulate_outer(t, arena, vin, out)
     assert np.allclose(out, ref, rtol=0, atol=1e-11 * max(1.0, np.abs(ref).max()))
 
 
@@ -135,12 +136,12 @@ def test_outer_validation(built):
     t = np.zeros(1, OUTER_TERM_DTYPE)
     t[0] = (3, 4, 4, 1, 0, 0, 4, 0, 2, (0, 0), 1.0, 0, 0, 0)
     arena, vin, out = np.zeros(12), np.zeros(1), np.zeros(12)
-    capi.debug_compile_and_emulate_outer(t, arena, vin, out)
+    hooks.debug_compile_and_emulate_outer(t, arena, vin, out)
     for field, val in (("ldc", 3), ("c_off", 1), ("a_off", 1), ("a_src", 3), ("m", 0)):
         bad = t.copy()
         bad[field] = val
         with pytest.raises(capi.B2XError):
-            capi.debug_compile_and_emulate_outer(bad, arena, vin, out)
+            hooks.debug_compile_and_emulate_outer(bad, arena, vin, out)
 
 
 def test_host_mirror_records_block_products(built):

@@ -40,3 +40,11 @@ def test_no_cpu_fallback_without_device(built):
         capi.device_init(0)
     with pytest.raises(capi.B2XError):
         capi.Arena.from_host([np.zeros(8)])
+
+
+def test_product_library_carries_no_host_emulator(built):
+    """the host evaluation of compiled plans lives in tests/native/libb2x_testhooks.so, not in the shipped library"""
+    lib = capi.lib()
+    for name in ("b2x_debug_compile_and_emulate", "b2x_debug_compile_and_emulate_gemms",
+                 "b2x_debug_compile_and_emulate_outer", "b2x_debug_compile_diag"):
+        assert not hasattr(lib, name), name

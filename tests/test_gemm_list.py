@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+import hooks
 from conftest import GOLDEN
 
 
@@ -112,12 +113,12 @@ def test_compiled_gemm_list_matches_reference(built, fn):
 
     gl = read_gemm_list(fn)
     out = np.zeros(gl.out_len)
-    st = capi.debug_compile_and_emulate_gemms(gl.gemms, gl.in_len, gl.out_len, gl.arena, gl.vin, out, keep_order=1)
+    st = hooks.debug_compile_and_emulate_gemms(gl.gemms, gl.in_len, gl.out_len, gl.arena, gl.vin, out, keep_order=1)
     assert st["macs"] == gl.macs and st["macs_executed"] == gl.macs  # record by record, as the reference replays it
     assert np.abs(out - gl.out_ref).max() <= 1e-12 * max(1.0, np.abs(gl.out_ref).max())
     # shipped: operator blocks that meet the same psi block in the same output window are summed first
     out = np.zeros(gl.out_len)
-    st = capi.debug_compile_and_emulate_gemms(gl.gemms, gl.in_len, gl.out_len, gl.arena, gl.vin, out)
+    st = hooks.debug_compile_and_emulate_gemms(gl.gemms, gl.in_len, gl.out_len, gl.arena, gl.vin, out)
     assert st["macs"] == gl.macs and st["macs_executed"] <= gl.macs
     assert np.abs(out - gl.out_ref).max() <= 1e-12 * max(1.0, np.abs(gl.out_ref).max())
 
@@ -132,7 +133,7 @@ def test_compiled_gemm_list_random(built, seed, item_macs):
     ref = rng.standard_normal(out_len)
     out = ref.copy()
     numpy_gemm_list(g, arena, vin, ref, -1.3)
-    st = capi.debug_compile_and_emulate_gemms(g, in_len, out_len, arena, vin, out, -1.3, item_macs=item_macs)
+    st = hooks.debug_compile_and_emulate_gemms(g, in_len, out_len, arena, vin, out, -1.3, item_macs=item_macs)
     assert st["n_items"] >= st["n_tiles"] > 0
     assert np.allclose(out, ref, rtol=0, atol=1e-10 * max(1.0, np.abs(ref).max()))
 
@@ -172,7 +173,7 @@ def test_operator_sums_are_shared_between_psi_blocks(built, tb):
         arena, vin = rng.standard_normal(arena_len), rng.standard_normal(in_len)
         ref, out = np.zeros(out_len), np.zeros(out_len)
         numpy_gemm_list(g, arena, vin, ref)
-        st = capi.debug_compile_and_emulate_gemms(g, in_len, out_len, arena, vin, out)
+        st = hooks.debug_compile_and_emulate_gemms(g, in_len, out_len, arena, vin, out)
         assert np.abs(out - ref).max() <= 1e-12 * np.abs(ref).max()
         assert st["macs_executed"] == sum(m * n * k for m in ms)  # one product per psi block
         res[proportional] = st["device_bytes"]
@@ -187,12 +188,12 @@ def test_gemm_list_validation(built):
     g = np.zeros(1, GEMM_DTYPE)
     g[0] = (4, 4, 4, 4, 4, 4, 0, 0, 0, 1, 0, 1.0, 0, 0, 0)
     arena, vin, out = np.zeros(16), np.zeros(16), np.zeros(16)
-    capi.debug_compile_and_emulate_gemms(g, 16, 16, arena, vin, out)
+    hooks.debug_compile_and_emulate_gemms(g, 16, 16, arena, vin, out)
     for field, val in (("lda", 3), ("c_off", 1), ("b_off", 1), ("ta", 2), ("k", 0)):
         bad = g.copy()
         bad[field] = val
         with pytest.raises(capi.B2XError):
-            capi.debug_compile_and_emulate_gemms(bad, 16, 16, arena, vin, out)
+            hooks.debug_compile_and_emulate_gemms(bad, 16, 16, arena, vin, out)
 
 
 def test_struct_fixture_roundtrip(built, tmp_path):

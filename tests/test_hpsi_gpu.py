@@ -103,15 +103,59 @@ def test_hermitian_effective_hamiltonian(gpu):
     assert abs(x @ hy - hx @ y) <= 1e-10 * max(1.0, abs(x @ hy))
 
 
-def test_config1_scale_h10_m500(gpu):
-    """BASELINE configs[1] size class: the H10 structure captured at M=50 scaled x10 (M=500-like blocks),
-    random data, against the oracle (0.6 GMAC-class replay)."""
-    pf = read_plan([f for f in FILES if "h10szm50.sw0.site6" in f][0])
-    big = fill_plan(synth.scale_plan(pf, 6), 9)
-    ref = np.zeros(big.sigma_len)
-    oracle.replay(big.pairs, big.arena, big.psi, ref, 1.0, 8)
-    sig, st = _run(gpu, big)
+def _struct(name):
+    from block2_preview_amd.planfile import read_struct_npz
+
+    return read_struct_npz(os.path.join(os.path.dirname(FILES[0]), name))
+
+
+def _vs_oracle(gpu, pf, seed, threads=16, **kw):
+    pf = fill_plan(pf, seed)
+    ref = np.zeros(pf.sigma_len)
+    oracle.replay(pf.pairs, pf.arena, pf.psi, ref, 1.0, threads)
+    sig, st = _run(gpu, pf, **kw)
+    assert st["fallback"] == 0 and st["macs"] == pf.macs
     assert _close(sig, ref), st
+    return sig, st
+
+
+def test_config1_h10_m500_true_structure(gpu):
+    """BASELINE configs[1] at its TRUE size: the H.psi plan the reference records for H10/STO-6G, SZ, M=500 at the
+    mid-chain site (8 276 pairs, 0.48 GMAC: tests/golden/h10_sz_m500_sw1_site4.struct.npz, captured by oracle/ref_dump
+    from the running reference), synthetic operator / psi data, against the oracle on every path."""
+    pf = _struct("h10_sz_m500_sw1_site4.struct.npz")
+    assert len(pf.pairs) == 8276 and pf.macs == 483096896
+    sig, st = _vs_oracle(gpu, pf, 9)
+    _vs_oracle(gpu, pf, 9, keep_order=1)
+    _vs_oracle(gpu, pf, 9, two_stage=-1)  # all sectors on the fused wave kernel
+    again, _ = _run(gpu, pf)
+    assert np.array_equal(again, sig)
+
+
+def test_config1_scale_h10_m500(gpu):
+    """the H10 structure captured WITH DATA at M=50 (golden, sigma_ref inside) scaled x10 to the M=500 block sizes,
+    random data, against the oracle (2.6 GMAC replay)"""
+    pf = read_plan([f for f in FILES if "h10szm50.sw0.site6" in f][0])
+    _vs_oracle(gpu, synth.scale_plan(pf, 10), 9)
+
+
+def test_config5_hubbard_l16_m3000_true_structure(gpu):
+    """BASELINE configs[4] at its TRUE size: the plan the reference records for the 1D Hubbard chain L=16, U/t=4, SZ at
+    M=3000 (sweep 0 from MPS::random_canonicalize at fixed M, two-site step 7-8: 692 pairs, 54 GMAC, 415 MB of operators,
+    psi of 6.4 M elements; tests/golden/hubbard_l16_u4_sz_m3000_sw0_site7.struct.npz), synthetic data.  The oracle replays
+    the FULL plan on the host cores (about 10 s), so parity at this size is direct, not by properties."""
+    pf = _struct("hubbard_l16_u4_sz_m3000_sw0_site7.struct.npz")
+    assert len(pf.pairs) == 692 and pf.macs == 53960716386
+    pf = fill_plan(pf, 21)
+    ref = np.zeros(pf.sigma_len)
+    oracle.replay(pf.pairs, pf.arena, pf.psi, ref, 1.0, 16)
+    sig, st = _run(gpu, pf)
+    assert st["fallback"] == 0 and st["macs_issued"] > 0
+    assert _close(sig, ref), st
+    sig2, st2 = _run(gpu, pf, keep_order=1)
+    assert st2["macs_executed"] == pf.macs and _close(sig2, ref), st2
+    again, _ = _run(gpu, pf)
+    assert np.array_equal(again, sig)
 
 
 @pytest.mark.parametrize("fn", FILES, ids=[os.path.basename(f) for f in FILES])
@@ -181,28 +225,31 @@ def test_edge_cases(gpu):
     plan.close(), ar.close(), arena.close()
 
 
-def test_full_size_m4000_properties(gpu):
-    """BASELINE size (the bench workload: Cr2 plan x16 -> M=4000, 98 722 pairs, 20.7 TMAC, 73 GB of operators): the oracle
-    cannot visit it, so the MFMA path is checked through size-independent properties: linearity in psi, bitwise
-    repeatability, and agreement with the independent per-pair atomic kernel (hpsi_generic) on the same device data."""
+@pytest.mark.parametrize("scale", [8, 16], ids=["cr2_m2000", "cr2_m4000"])
+def test_full_size_cr2_properties(gpu, scale):
+    """BASELINE sizes of the Cr2/SVP SU2 mid-chain plan: x8 -> M=2000 (configs[2]: 2.6 TMAC, 9.2 GB of operators) and
+    x16 -> M=4000 (configs[3], the bench workload: 98 722 pairs, 20.7 TMAC, 73 GB of operators).  The oracle cannot visit
+    these, so the MFMA path is checked through size-independent properties: linearity in psi, bitwise repeatability,
+    agreement with the reference's order of operations (keep_order = 1) and with the independent per-pair atomic kernel
+    (hpsi_generic) on the same device data."""
     import torch
 
     from block2_preview_amd.planfile import read_struct_npz
 
     base = read_struct_npz(os.path.join(os.path.dirname(FILES[0]), "cr2_su2_m250_sw1_site20.struct.npz"))
-    full = synth.scale_plan(base, 16)
+    full = synth.scale_plan(base, scale)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(5)
-    arena_t = torch.empty(full.arena_len + 8, dtype=torch.float64, device=dev)
+    arena_t = torch.empty(full.arena_len, dtype=torch.float64, device=dev)
     for a in range(0, full.arena_len, 1 << 28):
         arena_t[a:a + (1 << 28)].uniform_(-0.5, 0.5, generator=g)
-    x = torch.empty(full.psi_len + 8, dtype=torch.float64, device=dev).uniform_(-0.5, 0.5, generator=g)
-    y = torch.empty(full.psi_len + 8, dtype=torch.float64, device=dev).uniform_(-0.5, 0.5, generator=g)
+    x = torch.empty(full.psi_len, dtype=torch.float64, device=dev).uniform_(-0.5, 0.5, generator=g)
+    y = torch.empty(full.psi_len, dtype=torch.float64, device=dev).uniform_(-0.5, 0.5, generator=g)
     z = 0.3 * x - 1.7 * y
     arena = gpu.Arena.adopt_device(arena_t.data_ptr(), full.arena_len, keep=arena_t)
     plan = gpu.Plan(arena, full.pairs, full.psi_len, full.sigma_len)
-    assert plan.stats["macs"] == full.macs
+    assert plan.stats["macs"] == full.macs and plan.stats["fallback"] == 0 and plan.stats["n_staged"] == 0
     s = torch.cuda.current_stream().cuda_stream
 
     def apply(v, **kw):

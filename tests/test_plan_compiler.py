@@ -7,6 +7,7 @@ import os
 import numpy as np
 import pytest
 
+import hooks
 from conftest import fill_plan, golden_plan_files
 from block2_preview_amd import capi, synth
 from block2_preview_amd.planfile import PAIR_DTYPE, read_plan
@@ -19,7 +20,7 @@ def _check(pf, **kw):
     ref = np.zeros(pf.sigma_len)
     oracle.replay(pf.pairs, pf.arena, pf.psi, ref, 0.75)
     sig = np.zeros(pf.sigma_len)
-    st, fb = capi.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, pf.arena, pf.psi, sig, 0.75, **kw)
+    st, fb = hooks.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, pf.arena, pf.psi, sig, 0.75, **kw)
     assert not fb
     assert st["macs"] == pf.macs
     assert np.abs(sig - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
@@ -56,18 +57,18 @@ def test_scaled_structure_consistent(built):
 
 
 def test_empty_and_invalid(built):
-    st, fb = capi.debug_compile_and_emulate(np.zeros(0, PAIR_DTYPE), 10, 10, np.zeros(4), np.zeros(10), np.zeros(10))
+    st, fb = hooks.debug_compile_and_emulate(np.zeros(0, PAIR_DTYPE), 10, 10, np.zeros(4), np.zeros(10), np.zeros(10))
     assert st["n_pairs"] == 0 and not fb
     bad = np.zeros(1, PAIR_DTYPE)
     bad["m0"] = bad["n0"] = bad["k0"] = bad["m1"] = bad["n1"] = bad["k1"] = 4
     bad["lda0"] = bad["ldb0"] = bad["lda1"] = bad["ldc1"] = 4
     bad["x_off"] = 100  # runs past psi
     with pytest.raises(capi.B2XError):
-        capi.debug_compile_and_emulate(bad, 16, 16, np.zeros(32), np.zeros(16), np.zeros(16))
+        hooks.debug_compile_and_emulate(bad, 16, 16, np.zeros(32), np.zeros(16), np.zeros(16))
     bad["x_off"] = 0
     bad["ta0"] = 1  # unsupported on this path
     with pytest.raises(capi.B2XError):
-        capi.debug_compile_and_emulate(bad, 16, 16, np.zeros(32), np.zeros(16), np.zeros(16))
+        hooks.debug_compile_and_emulate(bad, 16, 16, np.zeros(32), np.zeros(16), np.zeros(16))
 
 
 @pytest.mark.parametrize("fn", FILES[:3], ids=[os.path.basename(f) for f in FILES[:3]])
@@ -103,3 +104,44 @@ def test_shared_products_and_association(built, seed, scratch_mb, keep_order):
     if not keep_order:  # operator pre-sums on top (second operators of pairs sharing a product and a window)
         st3 = _check(pf, two_stage=1, scratch_mb=scratch_mb, presum=1)
         assert st3["macs_executed"] <= st["macs_executed"]
+
+
+def test_degenerate_operands_at_buffer_ends_are_staged(built):
+    """K = 1 / one-row A operands whose 16-byte fetch would touch the element behind psi or the arena are read from a
+    staged copy in plan-owned memory (b2x_plan_stats.n_staged); everything else is read in place"""
+    rng = np.random.default_rng(77)
+    p = np.zeros(2, PAIR_DTYPE)
+    psi_len, arena_len, sigma_len = 50, 400, 40
+    p[0] = (7, 5, 1, 1, 5, 6, 5, 7, 7, 5, 0, 0, 0, 0, 0, 1.0, 0.5, psi_len - 7, 0, 10, 0)
+    z_off = arena_len - ((9 - 1) * 3 + 1)
+    p[1] = (9, 5, 4, 4, 5, 1, 5, 9, 3, 5, 0, 0, 1, 0, 0, 1.0, -1.5, 0, 100, z_off, 30)
+    pf = synth.random_rotate_plan(rng, 1, 2, 1)
+    pf.pairs, pf.psi_len, pf.sigma_len, pf.arena_len = p, psi_len, sigma_len, arena_len
+    pf.arena, pf.psi = rng.random(arena_len), rng.random(psi_len)
+    st = _check(pf, two_stage=1, keep_order=1)
+    assert st["n_staged"] == 2
+    p["x_off"][0] -= 1  # one element of room behind the operands: nothing to stage
+    p["z_off"][1] -= 1
+    st = _check(pf, two_stage=1, keep_order=1)
+    assert st["n_staged"] == 0
+
+
+def _all_structures():
+    import glob
+
+    from conftest import GOLDEN
+
+    return sorted(glob.glob(os.path.join(GOLDEN, "*.struct.npz")) + glob.glob(os.path.join(GOLDEN, "*.rotstruct.npz")))
+
+
+@pytest.mark.parametrize("fn", _all_structures(), ids=os.path.basename)
+def test_reference_plans_never_take_the_atomic_fallback(built, fn):
+    """every plan structure captured from the reference (N2, H10 M=500, Hubbard M=3000, Cr2 M=250 H.psi and rotations)
+    segments by output: the non-deterministic per-pair atomic kernel is never selected, nothing needs staging"""
+    from block2_preview_amd.planfile import read_struct_npz
+
+    pf = read_struct_npz(fn)
+    for kw in ({}, {"keep_order": 1}):
+        st, fb = hooks.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, None, None, None,
+                                                 arena_len=pf.arena_len, **kw)
+        assert not fb and st["fallback"] == 0 and st["n_staged"] == 0 and st["macs"] == pf.macs

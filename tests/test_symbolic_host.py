@@ -13,6 +13,7 @@ import os
 import numpy as np
 import pytest
 
+import hooks
 from conftest import GOLDEN
 from block2_preview_amd.planfile import PAIR_DTYPE, read_arrays
 from oracle import oracle
@@ -123,7 +124,7 @@ def test_diag_terms_segment_without_device(host, fn):
     h = host.SymbolicEffectiveHamiltonian(sym_of(fn), d)
     t = np.frombuffer(h.diag_terms().tobytes(), DIAG_TERM_DTYPE).copy()
     n = C.c_uint64()
-    capi.check(capi.lib().b2x_debug_compile_diag(C.c_size_t(len(t)), t.ctypes.data_as(C.c_void_p),
+    hooks.check(hooks.lib().b2x_debug_compile_diag(C.c_size_t(len(t)), t.ctypes.data_as(C.c_void_p),
                                                  C.c_size_t(len(d["diag"])), C.c_uint64(len(d["arena"])), C.byref(n)))
     k = int(d["ket.info"][0])
     assert n.value <= len(d["info.%d.quanta" % k])  # at most one component per psi sector
