@@ -178,6 +178,10 @@ def traffic_of(workload):
 
 def main():
     args = parse()
+    if os.environ.get("B2X_BENCH_WATCHDOG"):  # debugging aid: dump every thread's Python stack and exit after N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["B2X_BENCH_WATCHDOG"]), exit=True)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -187,9 +191,9 @@ def main():
         raise SystemExit("launch with --nproc-per-node equal to --gpus")
     log = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
     ndev = torch.cuda.device_count()
-    shared_card = local >= ndev  # rehearsal of the N>1 path on a 1-GPU box: the ranks share the card
-    if shared_card:
-        local = local % max(ndev, 1)
+    # rehearsal of the N>1 path on a box with fewer cards than ranks: the ranks share cards (every rank decides alike)
+    shared_card = world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev
+    local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from block2_preview_amd import capi, synth
@@ -228,16 +232,24 @@ def main():
         sfile, wname = args.struct, "pair plan %s x%d" % (os.path.basename(args.struct), scale)
     base = read_struct_npz(sfile if os.path.isabs(sfile) else os.path.join(GOLD, sfile))
     full = synth.scale_plan(base, scale) if scale != 1 else base
-    mine, arena_len = synth.compact_arena(synth.shard_pairs(full.pairs, rank, world))
+    mine, arena_len, runs = synth.compact_arena(synth.shard_pairs(full.pairs, rank, world), return_runs=True)
     log("plan: %d pairs (%d on rank 0), %.3f TMAC, psi %d, operators %.2f GB on rank 0, M=%d" % (
         len(full.pairs), len(mine), full.macs / 1e12, full.psi_len, arena_len * 8 / 1e9, M))
-    # synthetic data generated on the device: uniform [0,1) like Random::fill (src/core/utils.hpp:247-252)
-    g = torch.Generator(device=dev)
-    g.manual_seed(1969 + rank)
+    # synthetic data generated on the device: uniform [0,1) like Random::fill (src/core/utils.hpp:247-252).  An operator
+    # element is a function of its offset in the UNSHARDED arena (a 64-bit multiplicative hash), so a rank's blocks hold the
+    # same numbers in every decomposition and the summed sigma of N ranks equals the one-rank sigma
     arena_t = torch.empty(max(arena_len, 1), dtype=torch.float64, device=dev)
-    step = 1 << 28
+    old_start = torch.from_numpy(np.ascontiguousarray(runs[0], np.int64)).to(dev)
+    new_start = torch.from_numpy(np.ascontiguousarray(runs[1], np.int64)).to(dev)
+    step = 1 << 27
     for a in range(0, arena_len, step):
-        arena_t[a:a + step].uniform_(0.0, 1.0, generator=g)
+        e = min(arena_len, a + step)
+        idx = torch.arange(a, e, dtype=torch.int64, device=dev)
+        r = torch.searchsorted(new_start, idx, right=True) - 1  # the run an element of the compact arena belongs to
+        gidx = old_start[r] + (idx - new_start[r])
+        h = gidx * 6364136223846793005 + 1442695040888963407  # (wraps mod 2^64)
+        arena_t[a:e] = ((h >> 11) & 0x1FFFFFFFFFFFFF).to(torch.float64) * (1.0 / 9007199254740992.0)
+        del idx, r, gidx, h
     gp = torch.Generator(device=dev)
     gp.manual_seed(7)
     psi_t = torch.empty(full.psi_len, dtype=torch.float64, device=dev).uniform_(0.0, 1.0, generator=gp)

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void hpsi_wave(const DPart *__restrict__ pa
 // row-slice boundaries of the sector, so a segment's rows always cover its tile: only columns (B side)
 // and the k tail need masking, and both are applied to the B registers.
 template <int TMF, int CF, int NW, int KC, bool SB>
-__device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GSeg *__restrict__ segs,
+__device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr, double *lds, const GSeg *__restrict__ segs,
                                         const double *__restrict__ arena, const double *__restrict__ psi,
                                         double *__restrict__ scratch, double *__restrict__ slabs) {
     constexpr int TM = TMF * 16, NT = NW * 64;
@@ -246,28 +246,23 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     uint32_t va[NI];     // per DMA instruction: byte offset of this lane's granule from the chunk's A base
     uint32_t vb[CF][KS]; // byte offset of this lane's B element from the k-step's B base
     uint32_t astep = 1, bstep = 1;
-    uint32_t a_adj = 0;  // bytes the chunk's A base is moved back by (odd k tail, see lane_offsets)
     uint32_t bmask = 0;  // B mask of the chunk that is fetched next (columns; k tail)
     bool tail = false;   // the offsets in va / vb are those of the partial last chunk
     double salpha = 1.0; // SB (single-GEMM lists): per-segment factor, folded into the B fragments
     bool s_kmaj = false, cols_full = false, bmasked = false;
 
+    // A 16-byte A granule may reach ONE element behind its operand: a k-contiguous operand whose K is not a multiple of
+    // the chunk depth is read up to element K of every row, a row-contiguous one whose row count is not a multiple of 16
+    // up to row mr of every k.  Inside a buffer that element is the caller's own neighbouring (finite) data and meets a
+    // zeroed B lane; where it would lie OUTSIDE the buffer — the operand ends exactly at the end of an adopted arena or
+    // of psi — the plan compiler hands the kernel a staged copy instead (stage_residual_reads, b2x_plan.cpp), so no
+    // buffer needs slack.  (An exact variant of these offsets — last granule fetched one element earlier, B slots and
+    // the tile store following it — was measured: +13 % time at M=250, +6 % at M=500, because this per-segment
+    // arithmetic IS the bottleneck of short segments; profiles/README.md.)
     // per-lane offsets of the chunk at k offset kb of segment S: unclamped for a full chunk (valid for every full chunk
     // of the segment), clamped to the last k for the partial one
-    // No load ever leaves its operand: a 16-byte granule that would straddle the end of a row (odd k tail) or of the
-    // tile's rows (odd row count) is fetched one element EARLIER instead, and the consumer follows it:
-    //  * k-contiguous A, partial chunk with an odd number n of valid k: the last granule holds k = n-2, n-1 in its slots
-    //    n-1, n; the B side then masks slot n-1 and feeds k = n-1 through slot n (one common shift for the segment);
-    //  * row-contiguous (k-major) A with an odd number of rows: the last granule holds rows mr-2, mr-1 in the MFMA rows
-    //    mr-1, mr, and the tile store takes the last row from MFMA row mr (k-contiguous segments clamp rows >= mr to
-    //    row mr-1 anyway, so both layouts agree on MFMA row mr).
-    // Left over: K == 1 (k-contiguous) and mr == 1 (row-contiguous) still touch one element behind the operand; the
-    // plan compiler stages such an operand in plan-owned memory when that element would lie outside its buffer.
     auto lane_offsets = [&](const GSeg &S, int kb, bool part) __attribute__((always_inline)) {
-        const int n = S.K - kb; // valid k of this chunk (part: n < KC)
-        const bool odd = part && !s_kmaj && (n & 1) && (n > 1 || kb > 0);
-        a_adj = odd ? 8u : 0u; // odd tail: the chunk's A base moves one element back, the offsets one forward
-        const uint32_t akmax = (uint32_t)(n - 1) * astep; // relative to the chunk base
+        const uint32_t akmax = (uint32_t)(S.K - 1 - kb) * astep; // relative to the chunk base
 #pragma unroll
         for (int j = 0; j < NI; j++) {
             // granule G of the LDS image is written by lane `lane` of DMA instruction (wave, j)
@@ -275,24 +270,17 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
             uint32_t ro, ko;
             if (s_kmaj) { // fragment-major image [f][k][16 rows]: granule = rows (f*16 + 2p, +1) of one k
                 const int f = G / (KC * 8), kl = (G % (KC * 8)) >> 3, p2 = G & 7;
-                const int r2 = f * 16 + 2 * p2;
-                ro = (uint32_t)(r2 + 1 < S.mr ? r2 : max(S.mr - 2, 0));
+                ro = (uint32_t)min(f * 16 + 2 * p2, S.mr - 1);
                 ko = (uint32_t)kl * astep;
-                ko = part ? min(ko, akmax) : ko;
             } else { // image [TM rows][KC k]; granule slot gs of a row holds k = 2*(gs ^ swz(row)), +1
                 const int row = G / (KC / 2), gs = G % (KC / 2);
                 const int swz = KC == 16 ? ((row >> 1) & 7) : (row & 15);
                 ro = (uint32_t)min(row, S.mr - 1) * (uint32_t)S.a_sr;
-                const int k2 = 2 * (gs ^ swz);
-                if (!part)
-                    ko = (uint32_t)k2;
-                else if (odd) // (+1: relative to the base moved back by a_adj)
-                    ko = (uint32_t)((k2 < n - 1 ? k2 : n - 2) + 1);
-                else
-                    ko = (uint32_t)min(k2, max(n - 2, 0));
+                ko = (uint32_t)(2 * (gs ^ swz));
             }
-            va[j] = (ro + ko) * 8u;
+            va[j] = (ro + (part ? min(ko, akmax) : ko)) * 8u;
         }
+        const uint32_t bkmax = (uint32_t)(S.K - 1 - kb) * bstep;
         bmask = 0;
 #pragma unroll
         for (int q = 0; q < CF; q++) {
@@ -302,11 +290,8 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
 #pragma unroll
             for (int s = 0; s < KS; s++) {
                 // full chunk: the k-step's 4 s rows are in the scalar base; partial chunk: base = chunk start
-                const int js = 4 * s + g; // k slot of this lane
-                const int krel = (odd && js == n) ? n - 1 : min(js, n - 1);
-                const bool kin = odd ? (js < n - 1 || js == n) : js < n;
-                vb[q][s] = (co + (part ? (uint32_t)krel * bstep : (uint32_t)g * bstep)) * 8u;
-                bmask |= (uint32_t)(in && (!part || kin)) << (q * KS + s);
+                vb[q][s] = (co + (part ? min((uint32_t)(4 * s + g) * bstep, bkmax) : (uint32_t)g * bstep)) * 8u;
+                bmask |= (uint32_t)(in && (!part || kb + 4 * s + g < S.K)) << (q * KS + s);
             }
         }
         tail = part;
@@ -324,7 +309,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     };
     // the A half of a fetch: this wave's share of the LDS-DMA of the chunk at k offset kb into LDS buffer `As`
     auto fetch_dma = [&](int kb, double *As) __attribute__((always_inline)) {
-        const char *ba = (const char *)(sA + (uint64_t)((uint32_t)kb * astep)) - a_adj;
+        const char *ba = (const char *)(sA + (uint64_t)((uint32_t)kb * astep));
 #pragma unroll
         for (int j = 0; j < NI; j++)
             if (NG % NT == 0 || (wave * NI + j) * 64 < NG) // whole DMA instruction inside the image
@@ -440,7 +425,14 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
     uint32_t si = item.seg_begin;
     if (si < item.seg_end) {
         GSeg S = segs[si];
-        GSeg Sn = segs[min(si + 1, item.seg_end - 1)];
+        // The NEXT segment's descriptor (64 bytes = one scalar-cache line) is only touched one segment ahead, through a
+        // single dword that stays in one SGPR: holding the whole prefetched descriptor (16 SGPRs) next to the current
+        // one left the chunk loop short of scalar registers, and what it spilled it reloaded with VALU lane reads in every
+        // chunk, between the MFMAs.  The load at the switch then hits the scalar cache.
+        auto touch = [&](uint32_t i) __attribute__((always_inline)) {
+            return *(const uint32_t *)(segs + min(i, item.seg_end - 1));
+        };
+        uint32_t warm = touch(si + 1);
         int kb = 0, buf = 0;
         enter(S);
         fetch(0, lds);
@@ -466,8 +458,9 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
             const bool more = nsi < item.seg_end;
             if (early) {
                 if (more && nsi != si) {
-                    S = Sn; // descriptor prefetched one segment ahead: no scalar-load latency at the switch
-                    Sn = segs[min(nsi + 1, item.seg_end - 1)];
+                    asm volatile("" ::"s"(warm)); // (the touch of this descriptor has landed by now)
+                    S = segs[nsi];
+                    warm = touch(nsi + 1);
                     enter(S);
                 } else if (more && nkb + KC > S.K)
                     lane_offsets(S, nkb, true); // the segment's partial last chunk
@@ -479,8 +472,9 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
             __builtin_amdgcn_sched_barrier(0);
             if (!early) {
                 if (more && nsi != si) {
-                    S = Sn;
-                    Sn = segs[min(nsi + 1, item.seg_end - 1)];
+                    asm volatile("" ::"s"(warm));
+                    S = segs[nsi];
+                    warm = touch(nsi + 1);
                     enter(S);
                 } else if (more && nkb + KC > S.K)
                     lane_offsets(S, nkb, true);
@@ -500,30 +494,27 @@ __device__ __forceinline__ void gg_body(const GItem &item, double *lds, const GS
         }
     }
     // ---- store the tile ----
-    double *out = (item.out_kind ? scratch : slabs) + item.out_off;
-    // an odd number of rows: the last row was accumulated in MFMA row `rows` (see lane_offsets), MFMA row rows-1 is void
-    const int r_lim = (item.rows & 1) ? item.rows - 1 : item.rows, r_alt = (item.rows & 1) ? item.rows : -1;
+    // The item descriptor is read AGAIN here (through a pointer the compiler cannot trace) instead of staying in scalar
+    // registers across the main loop: the loop is short of SGPRs, and what it spills it reloads with VALU lane reads in
+    // every chunk, next to the MFMAs.
+    const GItem *ip_opaque = item_ptr;
+    asm volatile("" : "+s"(ip_opaque));
+    const GItem fin = *ip_opaque;
+    double *out = (fin.out_kind ? scratch : slabs) + fin.out_off;
 #pragma unroll
     for (int q = 0; q < CF; q++) {
         const int col = wave * (CF * 16) + q * 16 + c;
-        if (col < item.cols) {
+        if (col < fin.cols) {
             // rows g, g + 4, g + 8, ...: a running pointer (one add per store, no 64-bit multiply); only the tile's last
             // row fragment can be cut short (rows > 16 (TMF - 1) by construction), so only it tests the row
-            double *po = out + (int64_t)g * item.out_ld + col;
-            const int64_t step = (int64_t)4 * item.out_ld;
+            double *po = out + (int64_t)g * fin.out_ld + col;
+            const int64_t step = (int64_t)4 * fin.out_ld;
 #pragma unroll
             for (int f = 0; f < TMF; f++)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    if (f < TMF - 1)
-                        *po = item.alpha * acc[f][q][r];
-                    else {
-                        const int i = f * 16 + 4 * r + g;
-                        if (i < r_lim)
-                            *po = item.alpha * acc[f][q][r];
-                        else if (i == r_alt)
-                            *(po - item.out_ld) = item.alpha * acc[f][q][r];
-                    }
+                    if (f < TMF - 1 || f * 16 + 4 * r + g < fin.rows)
+                        *po = fin.alpha * acc[f][q][r];
                     po += step;
                 }
         }
@@ -548,14 +539,14 @@ __global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__
 #define B2X_GG_CASE(T)                                                                                                 \
     case T:                                                                                                            \
         if constexpr (T * 16 <= kGGTileM)                                                                              \
-            gg_body<T, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);                                   \
+            gg_body<T, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);                                   \
         break;
     switch ((item.rows + 15) >> 4) { // row fragments of the tile
         B2X_GG_CASE(1) B2X_GG_CASE(2) B2X_GG_CASE(3) B2X_GG_CASE(4) B2X_GG_CASE(5) B2X_GG_CASE(6) B2X_GG_CASE(7)
         B2X_GG_CASE(8) B2X_GG_CASE(9) B2X_GG_CASE(10) B2X_GG_CASE(11) B2X_GG_CASE(12) B2X_GG_CASE(13) B2X_GG_CASE(14)
         B2X_GG_CASE(15)
     default:
-        gg_body<kGGTileM / 16, CF, NW, KC, SB>(item, lds, segs, arena, psi, scratch, slabs);
+        gg_body<kGGTileM / 16, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);
     }
 #undef B2X_GG_CASE
 }

@@ -135,24 +135,27 @@ std::vector<Component> build_components(std::vector<Window> &win, bool &fallback
 
 // Every slot of the scratch (a W product, a sum, a staged operand) is followed by at least one padding element that no
 // kernel ever writes (it stays zero from the allocation on): the one element a degenerate K = 1 / one-row operand
-// fetch may touch behind the slot.  Returns the slot's footprint (even: slots stay 16-byte aligned).
+// fetch may touch behind the slot.  Returns the slot's footprint, a multiple of 16 elements: every slot starts on a
+// 128-byte line, so the rows of a W whose width is a multiple of 16 never straddle cache lines.
 inline uint64_t slot_elems(CompiledPlan &out, uint64_t off, uint64_t size) {
     out.scratch_pads.push_back(off + size);
-    return (size + 2) & ~(uint64_t)1;
+    return (size + 16) & ~(uint64_t)15;
 }
 
-// see StageCopy (b2x_plan.hpp): called once all segments of a plan exist
+// see StageCopy (b2x_plan.hpp): called once all segments of a plan exist.  The kernel's A fetch (gg_body::lane_offsets)
+// reaches one element behind an operand whose K (k-contiguous layout) is not a multiple of the 16-deep chunk, or whose row
+// count (row-contiguous layout) is not a multiple of 16.
 void stage_residual_reads(CompiledPlan &out, uint64_t arena_cap, uint64_t in_cap) {
     std::map<std::pair<uint64_t, uint64_t>, uint64_t> done[2]; // (offset, extent) -> scratch offset, per source
     for (GSeg &g : out.gsegs) {
         if (g.a_src > 1)
-            continue; // the scratch is plan-owned: slack behind it, always finite (zeroed when allocated)
+            continue; // the scratch is plan-owned: every slot is followed by a zero, and it only holds finite values
         const bool kmaj = g.a_sk != 1;
-        if (!(kmaj ? g.mr == 1 : g.K == 1))
-            continue;
+        if ((kmaj ? g.mr : g.K) % 16 == 0)
+            continue; // whole granules only
         const uint64_t ext = (uint64_t)(g.mr - 1) * (uint64_t)g.a_sr + (uint64_t)(g.K - 1) * (uint64_t)g.a_sk + 1;
         if (g.a_off + ext + 1 <= (g.a_src == 0 ? arena_cap : in_cap))
-            continue;
+            continue; // the element behind the operand is inside the buffer
         auto key = std::make_pair(g.a_off, ext);
         auto it = done[g.a_src].find(key);
         if (it == done[g.a_src].end()) {
@@ -864,7 +867,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 continue;
             }
             const uint64_t wexact = cd.flip ? (uint64_t)p.m1 * p.k0 : (uint64_t)p.k1 * p.n0;
-            if (used - aux_len + wexact + 2 > budget && !cur.empty()) // (the budget bounds the per-step part of the scratch)
+            if (used - aux_len + wexact + 16 > budget && !cur.empty()) // (the budget bounds the per-step part of the scratch)
                 flush();
             const uint64_t wsz = slot_elems(out, used, wexact);
             cur.push_back(PW{cd.c, cd.wi, used, cd.flip, true});

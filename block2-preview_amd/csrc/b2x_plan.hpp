@@ -96,11 +96,11 @@ struct OWork {
 static_assert(sizeof(OWork) == 40, "OWork layout");
 static const int kOuterTileCols = 64;
 
-// The grouped-GEMM kernel fetches A operands as 16-byte granules.  It never reads outside an operand except in two
-// degenerate shapes (gg_body::lane_offsets): a k-contiguous operand with K == 1 and a row-contiguous one with a single
-// row touch ONE element behind the operand.  Where that element would lie outside the source buffer (an operand that
-// ends exactly at the end of an adopted arena or of the caller's psi), the operand is copied into plan-owned memory that
-// has a zero behind it, and the segment reads the copy.
+// The grouped-GEMM kernel fetches A operands as 16-byte granules and may reach ONE element behind an operand
+// (gg_body::lane_offsets).  Inside a buffer that element is neighbouring data that meets a zeroed B lane.  Where it
+// would lie OUTSIDE the source buffer (an operand that ends exactly at the end of an adopted arena or of the caller's
+// psi), the operand is copied into plan-owned memory that has a zero behind it, and the segment reads the copy: the
+// caller's buffers need no slack.
 struct StageCopy {
     uint32_t src;     // 0 = operator arena, 1 = input vector
     uint64_t src_off; // element offset in the source buffer

@@ -215,9 +215,10 @@ def shard_pairs(pairs, rank, world):
     return pairs[owner[inv] == rank]
 
 
-def compact_arena(pairs):
+def compact_arena(pairs, return_runs=False):
     """Renumber y_off / z_off so that only the operator blocks these pairs reference remain, packed
-    back to back (what one sum-MPO rank actually holds).  Returns (pairs, arena_len)."""
+    back to back (what one sum-MPO rank actually holds).  Returns (pairs, arena_len), and with return_runs the map of
+    the packing as well: (old_start, new_start, length) of every contiguous run that was kept."""
     p = pairs.copy()
     ey = np.where(p["tb0"] == 1, (p["n0"].astype(np.int64) - 1) * p["ldb0"] + p["k0"],
                   (p["k0"].astype(np.int64) - 1) * p["ldb0"] + p["n0"])
@@ -242,4 +243,6 @@ def compact_arena(pairs):
     n = len(p)
     p["y_off"] = new_start[:n].astype(np.uint64)
     p["z_off"] = new_start[n:].astype(np.uint64)
+    if return_runs:
+        return p, int(run_new[-1]), (run_start, run_new[:-1], run_len)
     return p, int(run_new[-1])

@@ -84,8 +84,9 @@ typedef struct b2x_plan_stats {
     uint64_t macs_issued;     /* MFMA issue slots x 1024 of the two-stage path incl. tile padding (0 if unused) */
     uint64_t fallback;        /* 1: the output windows could not be segmented, the plan runs on the per-pair atomic kernel
                                  (not bitwise reproducible); 0 for every plan the reference's DMRG records */
-    uint64_t n_staged;        /* operands copied into plan-owned memory because a 16-byte fetch would otherwise touch an
-                                 element behind the caller's buffer (degenerate K = 1 / one-row operands at a buffer end) */
+    uint64_t n_staged;        /* operands copied into plan-owned memory because a 16-byte fetch would otherwise touch the
+                                 element behind the caller's buffer (operands that end exactly at the end of psi or of an
+                                 adopted arena): arena operands once at plan creation, psi operands per execute */
 } b2x_plan_stats;
 
 /* tuning knobs; pass NULL for defaults */
@@ -132,7 +133,8 @@ int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, cons
 /* sigma += scale * H * psi.  on_device != 0: psi/sigma are device pointers (no copies);
  * stream: hipStream_t (NULL = default stream).  Asynchronous when on_device != 0.
  * Exactly psi_len elements of psi, sigma_len of sigma and the arena's len elements are accessed: buffers need no
- * slack (the kernels fetch 16-byte granules, but never one that leaves its operand; see b2x_plan_stats.n_staged). */
+ * slack (the kernels fetch 16-byte granules; an operand at the very end of a buffer is read from a copy the plan
+ * stages in its own memory, see b2x_plan_stats.n_staged). */
 int b2x_plan_execute(b2x_plan *p, const double *psi, double *sigma, double scale, int on_device,
                      void *stream);
 int b2x_plan_get_stats(const b2x_plan *p, b2x_plan_stats *st);

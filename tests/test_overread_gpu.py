@@ -1,9 +1,10 @@
-"""The kernels fetch operands as 16-byte granules but must never consume (or touch) anything outside an operand:
-psi, the arena and the input vector of a GEMM list are placed between NaN guard bands and handed over with their EXACT
-length (no slack), and under B2X_DEBUG_POISON=1 the library fills everything it allocates itself — the slack behind owned
-buffers, the whole W scratch before its first use — with NaN.  A stray read multiplies a NaN into the result (0 * NaN =
+"""The kernels fetch operands as 16-byte granules but must never touch anything outside the caller's buffers, nor
+consume anything a kernel has not written: psi, the arena and the input vector of a GEMM list are placed between NaN guard
+bands and handed over with their EXACT length (no slack), and under B2X_DEBUG_POISON=1 the library fills everything it
+allocates itself — the slack behind owned buffers, the whole W scratch before its first use (except the padding element
+behind every slot, which production keeps zero) — with NaN.  A stray read multiplies a NaN into the result (0 * NaN =
 NaN), so equality with the oracle proves there is none.  Shapes: odd dimensions, K not a multiple of 16, both operand
-layouts, degenerate K = 1 / one-row operands at the very end of a buffer (those are staged, b2x_plan_stats.n_staged)."""
+layouts, operands that end exactly at the end of a buffer (those are staged, b2x_plan_stats.n_staged)."""
 import os
 
 import numpy as np
@@ -90,7 +91,7 @@ def test_degenerate_operands_at_buffer_ends_are_staged(gpu, monkeypatch, poison)
     pf.pairs, pf.psi_len, pf.sigma_len, pf.arena_len = p, psi_len, sigma_len, arena_len
     pf.arena, pf.psi = rng.random(arena_len), rng.random(psi_len)
     st = _check(gpu, pf, two_stage=1, keep_order=1)
-    assert st["n_staged"] == 2, st
+    assert st["n_staged"] >= 2, st
     _check(gpu, pf, two_stage=1)
     _check(gpu, pf)
 

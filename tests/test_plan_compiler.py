@@ -107,8 +107,8 @@ def test_shared_products_and_association(built, seed, scratch_mb, keep_order):
 
 
 def test_degenerate_operands_at_buffer_ends_are_staged(built):
-    """K = 1 / one-row A operands whose 16-byte fetch would touch the element behind psi or the arena are read from a
-    staged copy in plan-owned memory (b2x_plan_stats.n_staged); everything else is read in place"""
+    """A operands whose 16-byte fetch would touch the element behind psi or the arena (they end exactly at the end of the
+    buffer) are read from a staged copy in plan-owned memory (b2x_plan_stats.n_staged); everything else is read in place"""
     rng = np.random.default_rng(77)
     p = np.zeros(2, PAIR_DTYPE)
     psi_len, arena_len, sigma_len = 50, 400, 40
@@ -137,11 +137,12 @@ def _all_structures():
 @pytest.mark.parametrize("fn", _all_structures(), ids=os.path.basename)
 def test_reference_plans_never_take_the_atomic_fallback(built, fn):
     """every plan structure captured from the reference (N2, H10 M=500, Hubbard M=3000, Cr2 M=250 H.psi and rotations)
-    segments by output: the non-deterministic per-pair atomic kernel is never selected, nothing needs staging"""
+    segments by output: the non-deterministic per-pair atomic kernel is never selected; at most the operands that end
+    the arena / psi are staged (no slack is assumed behind either buffer)"""
     from block2_preview_amd.planfile import read_struct_npz
 
     pf = read_struct_npz(fn)
     for kw in ({}, {"keep_order": 1}):
         st, fb = hooks.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, None, None, None,
                                                  arena_len=pf.arena_len, **kw)
-        assert not fb and st["fallback"] == 0 and st["n_staged"] == 0 and st["macs"] == pf.macs
+        assert not fb and st["fallback"] == 0 and st["n_staged"] <= 8 and st["macs"] == pf.macs
