@@ -234,6 +234,22 @@ class GemmPlan(Plan):
         self.psi_len, self.sigma_len = in_len, out_len
 
 
+def diag_build(arena, terms, diag, diag_len=None, on_device=False, stream=0):
+    """diag += sum of rank-1 diagonal terms (b2x_diag_term records as bytes or a structured array); `diag` is a host
+    numpy array or, with on_device, a device address of diag_len doubles"""
+    terms = np.ascontiguousarray(terms)
+    n_terms = terms.nbytes // 56
+    if not on_device:
+        diag_len = diag.size
+    check(lib().b2x_diag_build(arena._h, C.c_size_t(n_terms), _ptr(terms), C.c_size_t(diag_len), _ptr(diag),
+                               C.c_int(1 if on_device else 0), C.c_void_p(int(stream))))
+
+
+def memcpy_d2d(dst_ptr, src_ptr, n_elems):
+    """device-to-device copy of n_elems doubles (default stream)"""
+    check(lib().b2x_vec_copy(C.c_void_p(int(src_ptr)), C.c_void_p(int(dst_ptr)), C.c_size_t(n_elems), None))
+
+
 def outer_build(arena, terms, vin, vout, on_device=False, in_len=None, out_len=None, stream=0):
     """vout += sum of element-wise block-product terms (blocking: a (x) site operator, operator sums).  Host numpy arrays
     (copied through the device) or, with on_device, device pointers + explicit lengths."""

@@ -283,8 +283,8 @@ struct BatchGEMMSeq {
     void iadd(const GMatrix &a, const GMatrix &b, double scale = 1.0, bool conj = false, double cfactor = 1.0) {
         if (cfactor != 1.0)
             throw std::runtime_error("BatchGEMMSeq::iadd: only accumulation (cfactor == 1) is recorded on this path");
-        if (!conj)
-            push_outer(1, a.m * a.n, b.data, 0, 1, nullptr, 0, 0, a.data, a.m * a.n, scale);
+        if (!conj) // (recorded with the block's own shape: plain and transposed sums into one block then share a row grid)
+            push_outer(a.m, a.n, b.data, a.n, 1, nullptr, 0, 0, a.data, a.n, scale);
         else
             push_outer(b.n, b.m, b.data, 1, b.n, nullptr, 0, 0, a.data, a.n, scale);
     }
@@ -638,9 +638,15 @@ struct IterativeMatrixFunctions {
             store.emplace_back(new DeviceVector(n));
             return store.back()->p;
         };
-        std::vector<double *> bs(M), sg(M), tb(M), ts(M);
-        for (int i = 0; i < M; i++)
-            bs[i] = mk(), sg[i] = mk(), tb[i] = mk(), ts[i] = mk();
+        // the subspace vectors are allocated as the subspace grows (the reference holds 2 M vectors up front, :902-907;
+        // typical runs converge with m << M, and 4 M + 2 eager psi-sized vectors would be 15 GB at the M=4000 psi)
+        std::vector<double *> bs(M, nullptr), sg(M, nullptr), tb(M, nullptr), ts(M, nullptr);
+        auto ensure = [&](int i) {
+            if (bs[i] == nullptr)
+                bs[i] = mk(), sg[i] = mk(), tb[i] = mk(), ts[i] = mk();
+        };
+        for (int i = 0; i < k; i++)
+            ensure(i);
         double *q = mk(), *t = mk();
         auto dot = [&](const double *x, const double *y) {
             double r;
@@ -722,6 +728,7 @@ struct IterativeMatrixFunctions {
                 for (int j = 0; j < m; j++)
                     check(b2x_vec_axpy(-dot(bs[j], q), bs[j], q, n, nullptr));
                 check(b2x_vec_scal(1.0 / std::sqrt(dot(q, q)), q, n, nullptr));
+                ensure(m);
                 check(b2x_vec_copy(q, bs[m], n, nullptr));
                 m++;
             }

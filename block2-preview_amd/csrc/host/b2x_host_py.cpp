@@ -220,6 +220,24 @@ PYBIND11_MODULE(b2x_host, m) {
              },
              py::arg("ket"), py::arg("conv_thrd") = 5E-6, py::arg("max_iter") = 5000, py::arg("soft_max_iter") = -1,
              py::arg("deflation_min_size") = 2, py::arg("deflation_max_size") = 50, py::arg("iprint") = false);
+    // Davidson on a plan that is already resident on the device (a b2x_plan* from the C ABI, e.g. capi.Plan._h.value):
+    // diag and ket are device addresses of n doubles; ket is overwritten with the eigenvector.  Nothing but the
+    // Rayleigh-Ritz scalars crosses PCIe.  -> (eigenvalue, number of H.psi applications)
+    m.def("davidson_device",
+          [](uintptr_t plan, uintptr_t diag_dev, uintptr_t ket_dev, size_t n, double conv_thrd, int max_iter, int soft_max_iter,
+             int deflation_min_size, int deflation_max_size, bool iprint) {
+              b2x_plan *p = (b2x_plan *)plan;
+              auto f = [p](const double *b, double *s) { check(b2x_plan_execute(p, b, s, 1.0, 1, nullptr)); };
+              std::vector<double *> vs{(double *)ket_dev};
+              int ndav = 0;
+              std::vector<double> e = IterativeMatrixFunctions::davidson(f, (const double *)diag_dev, vs, n, ndav, conv_thrd,
+                                                                         max_iter, soft_max_iter, deflation_min_size,
+                                                                         deflation_max_size, iprint);
+              return py::make_tuple(e[0], ndav);
+          },
+          py::arg("plan"), py::arg("diag_dev"), py::arg("ket_dev"), py::arg("n"), py::arg("conv_thrd") = 5E-6,
+          py::arg("max_iter") = 5000, py::arg("soft_max_iter") = -1, py::arg("deflation_min_size") = 2,
+          py::arg("deflation_max_size") = 50, py::arg("iprint") = false);
     b2xh::bind_symbolic(m);
     m.def("device_init", [](int ordinal) { check(b2x_device_init(ordinal)); }, py::arg("ordinal") = 0);
     m.def("small_eigs", [](std::vector<double> a, int n) {

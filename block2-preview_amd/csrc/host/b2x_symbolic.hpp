@@ -458,6 +458,27 @@ template <typename S> struct OperatorFunctions {
             seq->tensor_product(a[(int)ci.ia[il]], conj & 1, b[(int)ci.ib[il]], (conj & 2) >> 1, c[(int)ci.ic[il]],
                                 scale * ci.factor[il], ci.stride[il]);
     }
+    // a += scale * op(b) sector by sector (OperatorFunctions::iadd, operator_functions.hpp:135-174): conj reads the
+    // transposed block of b and carries the transposition factor of the coupling (the sums of operators that
+    // TensorFunctions::numerical_transform forms at the NC -> CN switch of the conventional MPO)
+    void iadd(const SparseMatrix<S> &a, const SparseMatrix<S> &b, double scale = 1.0, bool conj = false) const {
+        if (std::fabs(b.factor * scale) < 1E-20)
+            return;
+        const S adq = a.info->delta_quantum, bdq = b.info->delta_quantum;
+        for (int ia = 0; ia < a.info->n; ia++) {
+            const S bra = a.info->quanta[ia].get_bra(adq), ket = a.info->quanta[ia].get_ket();
+            const S bq = conj ? bdq.combine(ket, bra) : bdq.combine(bra, ket);
+            if (bq.data == kInvalidLabel)
+                continue;
+            const int ib = b.info->find_state(bq);
+            if (ib < 0)
+                continue;
+            double factor = scale * b.factor;
+            if (conj)
+                factor *= cg.transpose_cg(bdq, bra, ket);
+            seq->iadd(a[ia], b[ib], factor, conj, 1.0);
+        }
+    }
     // c[ic] += scale * op(rot_bra[cq]) a[ia] op(rot_ket[cq']) for every sector of c (operator_functions.hpp:175-210):
     // a is the operator in the enlarged basis (more sectors than c), the MPS tensor blocks are looked up by the bra /
     // ket labels of the c sector; trans = false: bra^T . a . ket (left blocks), true: bra . a . ket^T (right blocks)

@@ -411,6 +411,49 @@ template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
     return py::make_tuple(pa, v);
 }
 
+// Numerical transform from a symbolic-level fixture (oracle/ref_dump.cpp chain mode, `.entr`): the operators of one block
+// (infos, offsets into one vector) and, per new operator, the terms  new += factor * op  /  factor * op^T.
+// TensorFunctions::numerical_transform walks them through OperatorFunctions::iadd; the recorded element-wise terms read
+// and write the SAME vector (inputs and outputs are different operators); returned as b2x_outer_term records.
+template <typename S> py::array sym_transform(const py::dict &d) {
+    typedef SparseMatrixInfo<S> Info;
+    std::map<int, std::shared_ptr<Info>> cache;
+    const uint64_t *meta = SymEH<S>::template arr<uint64_t>(d, "meta");
+    std::vector<double> t((size_t)meta[3] + 1, 0.0); // address space of the block's vector (values are never read)
+    size_t n;
+    const int64_t *iid = SymEH<S>::template arr<int64_t>(d, "t.info", &n), *off = SymEH<S>::template arr<int64_t>(d, "t.off");
+    const double *fac = SymEH<S>::template arr<double>(d, "t.factor");
+    std::vector<std::shared_ptr<SparseMatrix<S>>> ops;
+    for (size_t i = 0; i < n; i++) {
+        auto m = std::make_shared<SparseMatrix<S>>();
+        m->info = SymEH<S>::info(d, (int)iid[i], cache);
+        m->factor = fac[i], m->data = off[i] < 0 ? nullptr : t.data() + off[i];
+        m->total_memory = off[i] < 0 ? 0 : m->info->get_total_memory();
+        ops.push_back(m);
+    }
+    size_t nn;
+    const int64_t *nop = SymEH<S>::template arr<int64_t>(d, "new.op", &nn), *tb = SymEH<S>::template arr<int64_t>(d, "new.term_begin");
+    const int64_t *top = SymEH<S>::template arr<int64_t>(d, "term.op"), *tcj = SymEH<S>::template arr<int64_t>(d, "term.conj");
+    const double *tf = SymEH<S>::template arr<double>(d, "term.factor");
+    auto seq = std::make_shared<BatchGEMMSeq>();
+    OperatorFunctions<S> opf(seq);
+    for (size_t k = 0; k < nn; k++)
+        for (int64_t j = tb[k]; j < tb[k + 1]; j++) {
+            if (nop[k] < 0 || top[j] < 0 || !ops[nop[k]]->data || !ops[top[j]]->data)
+                throw std::runtime_error("symbolic_transform: operator without data");
+            opf.iadd(*ops[nop[k]], *ops[top[j]], tf[j], tcj[j] != 0);
+        }
+    std::vector<b2x_outer_term> terms = seq->outer_terms;
+    for (size_t i = 0; i < terms.size(); i++) {
+        terms[i].a_src = 1, terms[i].a_off = (uint64_t)(seq->oa_ptr[i] - t.data());
+        terms[i].b_src = 2, terms[i].b_off = 0;
+        terms[i].c_off = (uint64_t)(seq->oc_ptr[i] - t.data());
+    }
+    py::array_t<uint8_t> pa(terms.size() * sizeof(b2x_outer_term));
+    std::memcpy(pa.mutable_data(), terms.data(), terms.size() * sizeof(b2x_outer_term));
+    return pa;
+}
+
 // SparseMatrix on-disk format of the reference (MPS tensors, operator blocks): load -> dict of arrays, and save
 template <typename S> py::dict sm_load(const std::string &fn) {
     SparseMatrix<S> m;
@@ -467,6 +510,13 @@ inline void bind_symbolic(py::module_ &m) {
             return sym_rotate<SU2>(d, execute);
         throw std::runtime_error("symmetry must be 'sz' or 'su2'");
     }, py::arg("sym"), py::arg("fixture"), py::arg("execute") = false);
+    m.def("symbolic_transform", [](const std::string &sym, const py::dict &d) {
+        if (sym == "sz")
+            return sym_transform<SZ>(d);
+        if (sym == "su2")
+            return sym_transform<SU2>(d);
+        throw std::runtime_error("symmetry must be 'sz' or 'su2'");
+    }, py::arg("sym"), py::arg("fixture"));
     py::class_<SymEHBase, std::shared_ptr<SymEHBase>>(m, "SymbolicEffectiveHamiltonian")
         .def(py::init([](const std::string &sym, const py::dict &d) -> std::shared_ptr<SymEHBase> {
             if (sym == "sz")

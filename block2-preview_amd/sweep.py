@@ -1,0 +1,395 @@
+"""Site-to-site DMRG chain on the device: the repo's own two-site sweep loop over block2's symbolic fixtures.
+
+What block2 does per site of a two-site sweep (DMRG::update_two_dot, src/dmrg/sweep_algorithm.hpp:811-1261, around
+MovingEnvironment::move_to / eff_ham, src/dmrg/moving_environment.hpp:1534-1570, 2062-2201, and
+left/right_contract_rotate, :226-442) is done here with every operator block resident in HBM from the first
+environment to the last site:
+
+    blocking   (TensorFunctions::left_contract / right_contract)      -> b2x_outer_build        (element-wise kernel)
+    rotation   (TensorFunctions::left_rotate / right_rotate)          -> b2x_plan_create/execute (grouped-GEMM kernels)
+    H_eff      (EffectiveHamiltonian ctor: plan + diagonal)           -> b2x_plan_create, b2x_diag_build
+    eigs       (IterativeMatrixFunctions::davidson)                   -> device-resident Davidson over b2x_plan_execute
+    split      (density matrix of psi, eigenvectors = new MPS tensor) -> host (numpy; a few small symmetric eigenproblems)
+
+The SYMBOLIC side of every step — operator infos, quantum-number bookkeeping, the expressions of the enlarged operators
+and of H_eff — belongs to block2's MPO / Partition layers, which are out of scope: it is taken as data from
+a chain fixture, i.e. the numbered sequence of blocking / rotation / effective-Hamiltonian events one reference run
+recorded (oracle/ref_dump.cpp chain=...; no operator or wavefunction data inside, only the site operators and the MPS
+tensors of the starting state).  The NUMERIC side — every operator block of every environment, the wavefunctions, the
+MPS tensors after the first decomposition, the energies — is this code's own: nothing numeric is read back from the
+reference after the initial environments.  The loop checks that the step it is about to do is the step the reference
+did (kind, sweep, site) and otherwise follows its own control flow.
+"""
+import glob
+import os
+import re
+import time
+
+import numpy as np
+
+from . import capi
+from .planfile import OUTER_TERM_DTYPE, PAIR_DTYPE, read_arrays
+
+
+class ChainFixture:
+    """<prefix>.ev<NNN>.<kind>.<ext> files + <prefix>.log of one reference run (ref_dump chain=<sweep> nodelay=1 nocache=1)"""
+
+    def __init__(self, prefix):
+        self.events = []
+        for fn in sorted(glob.glob(prefix + ".ev*")):
+            m = re.search(r"\.ev(\d+)\.([a-z]+)\.e[a-z]+$", fn)
+            if m:
+                self.events.append((int(m.group(1)), m.group(2), fn))
+        self.events.sort()
+        self.ref_energy, self.meta = {}, {}
+        for line in open(prefix + ".log"):
+            t = line.split()
+            if t and t[0] == "SITE_ENERGY":
+                self.ref_energy[(int(t[1]), int(t[2]))] = float(t[3])
+            elif t and t[0] == "EVENT":
+                self.meta[int(t[1])] = (t[2], int(t[3]), int(t[4]))
+            elif t and t[0] == "FINAL_ENERGY":
+                self.final_energy = float(t[1])
+        self.pos = 0
+
+    def next(self, *kinds):
+        n, kind, fn = self.events[self.pos]
+        if kind not in kinds:
+            raise RuntimeError("chain out of step: the reference did '%s' (event %d), this loop wants %s" % (kind, n, kinds))
+        self.pos += 1
+        return kind, read_arrays(fn)
+
+    def peek(self):
+        return self.events[self.pos][1] if self.pos < len(self.events) else None
+
+
+class OpTensor:
+    """operator blocks of one (enlarged or rotated) block in HBM: one device vector + {operator key: (offset, length)}"""
+
+    def __init__(self, n, layout):
+        self.buf = capi.DeviceBuffer(max(int(n), 1))
+        self.n, self.layout = int(n), layout
+
+    def close(self):
+        self.buf.close()
+
+
+def _info(d, i):
+    pre = "info.%d." % int(i)
+    q = d[pre + "quanta"].astype(np.uint64)
+    return {"q": q, "nbra": d[pre + "nbra"].astype(np.int64), "nket": d[pre + "nket"].astype(np.int64),
+            "ntot": d[pre + "ntot"].astype(np.int64), "dq": int(d[pre + "meta"][0]),
+            "len": int(d[pre + "meta"][3])}
+
+
+def _fields(q):
+    """packed SU2 / SZ label -> (n, twos_low, twos, pg); n is a signed 16-bit field (src/core/symmetry.hpp:1183-1306)"""
+    q = np.asarray(q, np.uint64)
+    n = ((q >> np.uint64(48)) & np.uint64(0xFFFF)).astype(np.int64)
+    n = np.where(n >= 32768, n - 65536, n)
+    return (n, ((q >> np.uint64(32)) & np.uint64(0xFFFF)).astype(np.int64),
+            ((q >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64), (q & np.uint64(0xFFFF)).astype(np.int64))
+
+
+class Timers(dict):
+    def add(self, k, t0):
+        self[k] = self.get(k, 0.0) + (time.perf_counter() - t0)
+
+
+class DMRG:
+    """two-site sweeps over a chain fixture; `sym` = "su2" (labels carry twos_low) or "sz".  Usage:
+        dm = DMRG(ChainFixture(prefix), "su2"); dm.init_environments(); e0 = dm.sweep(0, True); e1 = dm.sweep(1, False)"""
+
+    def __init__(self, fixture, sym, conv_thrd=1e-13, seed=1234):
+        from . import b2x_host
+
+        self.fx, self.sym, self.host = fixture, sym, b2x_host
+        self.conv_thrd, self.rng = conv_thrd, np.random.default_rng(seed)
+        self.L, self.R = {}, {}          # rotated blocks by the site their enlarged successor starts from
+        self.EL = self.ER = None         # current enlarged blocks
+        self.psi = None                  # (host wavefunction, its info, forward?) of the last solved site
+        self.energies, self.tm, self.n_sites = {}, Timers(), None
+        self.ndav = {}
+        self.n_zero_ops, self.zero_log = 0, []
+
+    # ---- steps ------------------------------------------------------------------------------------------------
+    def _assign(self, d):
+        """first block of a chain: the enlarged block IS the site operator tensor (left_assign / right_assign)"""
+        t0 = time.perf_counter()
+        site = np.ascontiguousarray(d["site"], np.float64)
+        bkey = {int(k): (int(o), int(l)) for k, o, l in zip(d["b.key"], d["b.off"], d["b.len"]) if o >= 0}
+        layout, host = {}, np.zeros(int(d["meta"][4]))
+        for k, i, o in zip(d["c.key"], d["c.info"], d["c.off"]):
+            if o < 0:
+                continue
+            n = _info(d, i)["len"]
+            so, sl = bkey[int(k)]
+            assert sl == n
+            host[o:o + n] = site[so:so + n]
+            layout[int(k)] = (int(o), n)
+        t = OpTensor(len(host), layout)
+        t.buf.upload(host)
+        self.tm.add("assign", t0)
+        return t
+
+    def _repack(self, src, keys, offs, lens, total):
+        """device vector of `total` elements holding operator `key` at `off` (the layout a fixture's step expects); the
+        source tensor is returned as it is when it already has that layout (the usual case: producer and consumer saw
+        the same memory in the reference)"""
+        want = {int(k): (int(o), int(l)) for k, o, l in zip(keys, offs, lens) if o >= 0 and l > 0}
+        if total == src.n and all(src.layout.get(k) == v for k, v in want.items()):
+            return src, False
+        out = OpTensor(total, want)
+        for k, (o, l) in want.items():
+            if k not in src.layout:  # allocated by the reference but never written (a symbol that is zero at this site)
+                self.n_zero_ops += 1
+                self.zero_log.append((self.fx.pos - 1, k, l))
+                continue
+            so, sl = src.layout[k]
+            assert sl == l, "operator %x: length %d here, %d expected" % (k, sl, l)
+            capi.memcpy_d2d(out.buf.ptr + 8 * o, src.buf.ptr + 8 * so, l)
+        return out, True
+
+    def _block(self, d, blk):
+        """enlarged block = block (x) site: symbolic_blocking records the element-wise terms, the device executes them"""
+        t0 = time.perf_counter()
+        right = bool(d["meta"][2])
+        pre = "rop" if right else "lop"  # the block-operator side of tensor_product's (lop, rop)
+        xl = int(d["x.len"][0])
+        lens = [(_info(d, i)["len"] if o >= 0 else 0) for i, o in zip(d[pre + ".info"], d[pre + ".off"])]
+        x, tmp = self._repack(blk, d[pre + ".key"], d[pre + ".off"], lens, xl)
+        dd = dict(d)
+        dd["x"] = np.zeros(xl)
+        terms, v = self.host.symbolic_blocking(self.sym, dd, False)
+        terms = np.frombuffer(np.asarray(terms).tobytes(), OUTER_TERM_DTYPE)
+        layout = {int(k): (int(o), _info(d, i)["len"]) for k, i, o in zip(d["c.key"], d["c.info"], d["c.off"])}
+        out = OpTensor(len(v), layout)
+        site = capi.Arena.from_host([np.ascontiguousarray(d["site"], np.float64)])
+        capi.outer_build(site, terms, x.buf.ptr, out.buf.ptr, True, xl, len(v))
+        capi.device_sync()
+        site.close()
+        if tmp:
+            x.close()
+        self.tm.add("block", t0)
+        return out
+
+    def _rotate(self, d, enl, mps):
+        """rotated block = A^T . enlarged . A per operator sector: symbolic_rotate records the GEMM pairs"""
+        t0 = time.perf_counter()
+        xl, vl, al = int(d["meta"][5]), int(d["meta"][6]), int(d["meta"][7])
+        lens = [_info(d, i)["len"] for i in d["a.info"]]
+        x, tmp = self._repack(enl, d["a.key"], d["a.off"], lens, xl)
+        dd = dict(d)
+        dd["x"], dd["arena"] = np.zeros(xl), np.zeros(al)
+        pairs, v = self.host.symbolic_rotate(self.sym, dd, False)
+        pairs = np.frombuffer(np.asarray(pairs).tobytes(), PAIR_DTYPE)
+        assert len(mps) == al
+        arena = capi.Arena.from_host([np.ascontiguousarray(mps, np.float64)])
+        plan = capi.Plan(arena, pairs, xl, vl)
+        assert plan.stats["fallback"] == 0
+        layout = {int(k): (int(o), _info(d, i)["len"]) for k, i, o in zip(d["c.key"], d["c.info"], d["c.off"])}
+        out = OpTensor(vl, layout)
+        plan.execute_device(x.buf.ptr, out.buf.ptr, 1.0)
+        capi.device_sync()
+        plan.close(), arena.close()
+        if tmp:
+            x.close()
+        self.tm.add("rotate", t0)
+        return out
+
+    def _transform(self, d, rot):
+        """the NC -> CN switch of the conventional MPO at the middle of the chain: the rotated block gains new
+        (complementary) operators that are sums of its own operators or their transposes
+        (TensorFunctions::numerical_transform); the sums run on the device, in place in the block's vector"""
+        t0 = time.perf_counter()
+        total = int(d["meta"][3])
+        lens = [(_info(d, i)["len"] if o >= 0 else 0) for i, o in zip(d["t.info"], d["t.off"])]
+        have = {int(k): (int(o), int(l)) for k, o, l in zip(d["t.key"], d["t.off"], lens) if o >= 0 and l > 0}
+        out = OpTensor(total, have)  # zero-filled: the new operators start from zero
+        for k, (o, l) in have.items():
+            if k in rot.layout:
+                so, sl = rot.layout[k]
+                assert sl == l
+                capi.memcpy_d2d(out.buf.ptr + 8 * o, rot.buf.ptr + 8 * so, l)
+        terms = np.frombuffer(np.asarray(self.host.symbolic_transform(self.sym, d)).tobytes(), OUTER_TERM_DTYPE)
+        dummy = capi.Arena.from_host([np.zeros(1)])
+        capi.outer_build(dummy, terms, out.buf.ptr, out.buf.ptr, True, total, total)
+        capi.device_sync()
+        dummy.close(), rot.close()
+        self.tm.add("transform", t0)
+        return out
+
+    def _rotate_and_transform(self, d, enl, mps):
+        t = self._rotate(d, enl, mps)
+        while self.fx.peek() in ("lntr", "rntr", "lint", "rint"):  # operator sums formed inside the rotated block
+            t = self._transform(self.fx.next("lntr", "rntr", "lint", "rint")[1], t)
+        return t
+
+    def _eigs(self, d):
+        """H_eff of the site from the two enlarged blocks (all in HBM): plan + diagonal, then Davidson on the device"""
+        t0 = time.perf_counter()
+        al = int(d["arena.len"][0])
+        dd = dict(d)
+        dd["arena"] = np.zeros(al)
+        h = self.host.SymbolicEffectiveHamiltonian(self.sym, dd)
+        h.record()
+        pairs = np.frombuffer(np.asarray(h.pairs()).tobytes(), PAIR_DTYPE)
+        dterms = np.asarray(h.diag_terms())
+        kinfo = _info(d, d["ket.info"][0])
+        n = kinfo["len"]
+        self.tm.add("eff_ham.record", t0)
+        t0 = time.perf_counter()
+        arena_t = OpTensor(al, {})
+        for pre, blk in (("lopt", self.EL), ("ropt", self.ER)):
+            for k, o, l in zip(d[pre + ".key"], d[pre + ".off"], d[pre + ".len"]):
+                if o >= 0 and l > 0:
+                    if int(k) not in blk.layout:
+                        self.n_zero_ops += 1
+                        self.zero_log.append((self.fx.pos - 1, int(k), int(l)))
+                        continue
+                    so, sl = blk.layout[int(k)]
+                    assert sl == l
+                    capi.memcpy_d2d(arena_t.buf.ptr + 8 * int(o), blk.buf.ptr + 8 * so, int(l))
+        arena = capi.Arena.adopt_device(arena_t.buf.ptr, al, keep=arena_t)
+        plan = capi.Plan(arena, pairs, n, n)
+        assert plan.stats["fallback"] == 0
+        diag = capi.DeviceBuffer(n)
+        capi.diag_build(arena, dterms, diag.ptr, n, True)
+        self.tm.add("eff_ham.device", t0)
+        t0 = time.perf_counter()
+        # Initial guess.  block2 starts Davidson from the wavefunction of the previous site; this loop carries no
+        # wavefunction from site to site, so it starts from the low end of the diagonal (the usual Davidson guess) and
+        # checks the answer against the variational bound E0 <= min(diag): a Ritz pair with a tiny residual above that
+        # bound is an excited state the iteration fell into, and the site is solved again from the lowest diagonal entry.
+        dg = diag.download()
+        guess = 1.0 / (dg - dg.min() + 0.1) ** 2 + 1e-3 * self.rng.standard_normal(n)
+        ket = capi.DeviceBuffer(n, guess)
+        ndav = 0
+        for attempt in range(4):
+            e, nd = self.host.davidson_device(plan._h.value, diag.ptr, ket.ptr, n, self.conv_thrd, 5000)
+            ndav += nd
+            if e <= dg.min() + 1e-9:
+                break
+            guess = 1e-2 * self.rng.standard_normal(n)
+            guess[np.argsort(dg)[:attempt + 1]] += 1.0
+            ket.upload(guess)
+        psi = ket.download()
+        self.tm.add("eigs", t0)
+        if os.environ.get("B2X_SWEEP_DEBUG"):  # residual of the returned pair, and the diagonal as the kernels built it
+            sig = capi.DeviceBuffer(n)
+            plan.execute_device(ket.ptr, sig.ptr, 1.0)
+            capi.device_sync()
+            hs, dg = sig.download(), diag.download()
+            rq = float(psi @ hs) / float(psi @ psi)
+            print("   [debug] n=%d pairs=%d ndav=%d e=%.10f rayleigh=%.10f |r|=%.2e |psi|=%.6f diag[min,max]=%.3f,%.3f" % (
+                n, len(pairs), ndav, e, rq, np.linalg.norm(hs - rq * psi), np.linalg.norm(psi), dg.min(), dg.max()), flush=True)
+            sig.close()
+        plan.close(), arena.close(), arena_t.close(), diag.close(), ket.close()
+        return e + float(d["const_e"][0]), ndav, psi, kinfo, len(pairs)
+
+    def _split(self, d, right):
+        """new MPS tensor = the dominant eigenvectors of the density matrix of psi (DensityMatrix decomposition,
+        src/dmrg/moving_environment.hpp density_matrix / split_density_matrix), per quantum-number sector of the bond,
+        kept-state counts as in the fixture's tensor info (the bond dimension bookkeeping is block2's)"""
+        t0 = time.perf_counter()
+        psi, kinfo = self.psi
+        ainfo = _info(d, d["mps.info"][0])
+        out = np.zeros(int(d["meta"][7]))
+        base = int(d["mps.off"][0])
+        n, tl, tw, pg = _fields(kinfo["q"])
+        dn, _, _, dpg = _fields(np.array([kinfo["dq"]], np.uint64))
+        an, _, atw, apg = _fields(ainfo["q"])
+        if right:  # right label of a psi block: -ket  ->  (-n, twos, pg)
+            bn, btw, bpg = -n, tw, pg
+        else:      # left label: get_bra(dq)  ->  (n + dq.n, twos_low, pg ^ dq.pg)
+            bn, btw, bpg = n + dn[0], tl, pg ^ dpg[0]
+        for s in range(len(ainfo["q"])):
+            sel = np.nonzero((bn == an[s]) & (btw == atw[s]) & (bpg == apg[s]))[0]
+            rows, cols = int(ainfo["nbra"][s]), int(ainfo["nket"][s])
+            fused, kept = (cols, rows) if right else (rows, cols)
+            blocks = [psi[kinfo["ntot"][i]:kinfo["ntot"][i] + kinfo["nbra"][i] * kinfo["nket"][i]].reshape(
+                int(kinfo["nbra"][i]), int(kinfo["nket"][i])) for i in sel]
+            rho = np.zeros((fused, fused))
+            for b in blocks:
+                assert (b.shape[1] if right else b.shape[0]) == fused
+                rho += b.T @ b if right else b @ b.T
+            w, u = np.linalg.eigh(rho)
+            u = u[:, ::-1][:, :kept]  # largest weights first
+            blk = u.T if right else u
+            o = base + int(ainfo["ntot"][s])
+            out[o:o + rows * cols] = blk.reshape(-1)
+        self.tm.add("split", t0)
+        return out
+
+    # ---- the loop ---------------------------------------------------------------------------------------------
+    def init_environments(self):
+        """MovingEnvironment::init_environments (moving_environment.hpp:1245-): all right blocks of the starting state,
+        from the last site inwards, with the MPS tensors of the starting state (data of the fixture)"""
+        fx = self.fx
+        n_rot = sum(1 for n, k, _ in fx.events if k == "rrot" and fx.meta[n][1] < 0)
+        self.n_sites = n_rot + 2  # right blocks R[n-1] ... R[2] (the first two sites form the first wavefunction)
+        j = self.n_sites - 1
+        enl = self._assign(fx.next("rasg")[1])
+        while True:
+            d = fx.next("rrot")[1]
+            self.R[j] = self._rotate_and_transform(d, enl, d["arena"])
+            enl.close()
+            if j == 2:
+                break
+            enl = self._block(fx.next("rblk")[1], self.R[j])
+            j -= 1
+        return sorted(self.R)
+
+    def sweep(self, isw, forward):
+        """DMRG::sweep (sweep_algorithm.hpp:2550-2699) with update_two_dot per site; returns the site energies"""
+        fx, n = self.fx, self.n_sites
+        sites = range(0, n - 1) if forward else range(n - 2, -1, -1)
+        out = []
+        for i in sites:
+            t_site = time.perf_counter()
+            if forward:
+                if i > 0:  # move_to(i): rotate the enlarged left block of the previous site with the new MPS tensor
+                    _, d = fx.next("lasg", "lblk")   # (the reference re-contracts it; it is still in HBM here)
+                    _, d = fx.next("lrot")
+                    a = self._split(d, False)
+                    self.L[i] = self._rotate_and_transform(d, self.EL, a)
+                if self.EL is not None:
+                    self.EL.close()
+                if i == 0:
+                    self.EL = self._assign(fx.next("lasg")[1])
+                else:
+                    self.EL = self._block(fx.next("lblk")[1], self.L[i])
+                if self.ER is not None:
+                    self.ER.close()
+                if i == n - 2:
+                    self.ER = self._assign(fx.next("rasg")[1])
+                else:
+                    self.ER = self._block(fx.next("rblk")[1], self.R[i + 2])
+            else:
+                if i < n - 2:  # move_to(i): rotate the enlarged right block of the previous site
+                    _, d = fx.next("rasg", "rblk")
+                    _, d = fx.next("rrot")
+                    a = self._split(d, True)
+                    if i + 2 in self.R:
+                        self.R[i + 2].close()
+                    self.R[i + 2] = self._rotate_and_transform(d, self.ER, a)
+                if self.ER is not None:
+                    self.ER.close()
+                if i == n - 2:
+                    self.ER = self._assign(fx.next("rasg")[1])
+                else:
+                    self.ER = self._block(fx.next("rblk")[1], self.R[i + 2])
+                if self.EL is not None:
+                    self.EL.close()
+                if i == 0:
+                    self.EL = self._assign(fx.next("lasg")[1])
+                else:
+                    self.EL = self._block(fx.next("lblk")[1], self.L[i])
+            _, d = fx.next("eham")
+            assert (int(d["chain.meta"][0]), int(d["chain.meta"][1])) == (isw, i)
+            e, ndav, psi, kinfo, n_pairs = self._eigs(d)
+            self.psi = (psi, kinfo)
+            self.energies[(isw, i)], self.ndav[(isw, i)] = e, ndav
+            out.append(e)
+            self.tm.add("site_total", t_site)
+        return out

@@ -35,6 +35,9 @@
  *   prefactors=1                             (with para=) also write ParallelRuleSimple::index_prefactor of every (i,j), (i,j,k,l)
  *   para=i|ij                                sum-MPO parallel rule (ParallelRuleSimple I / IJ); under mpirun with the
  *                                            _HAS_MPI build every rank writes <outprefix>.r<rank>of<size>.*
+ *   chain=<last sweep>  nodelay=1  nocache=1  every blocking / rotation / effective Hamiltonian from the initial environments
+ *                                            up to that sweep at the symbolic level, numbered in call order, without bulk data
+ *                                            (fixtures of the site-to-site chain; needs nodelay=1)
  *   stop_after=<sweep>:<site>                leave the run right after the captures of that site (large-M structure runs)
  */
 #include "block2_core.hpp"
@@ -52,7 +55,32 @@ using namespace std;
 struct DumpSpec {
     set<pair<int, int>> with_data, structure, eham, pnoise, pnoise_struct, enoise, rot, rot_struct, erot, blk, blk_struct, eblk;
     string prefix;
+    // chain=<last sweep>: EVERY blocking, rotation and effective Hamiltonian of the run up to that sweep (the initial
+    // environments included) is written at the symbolic level, numbered in call order (<prefix>.ev<NNN>.<kind>), without
+    // the bulk data a replay produces itself (operators, wavefunctions): what remains are the infos, the expressions,
+    // operator keys, the site operators and — for the initial environments — the MPS tensors of the starting state
+    int chain = -2;
+    mutable int ev = 0;
+    mutable vector<string> *evlog = nullptr;
+    bool lite() const { return chain > -2; }
+    string next_event(const string &kind, int isw, int center) const {
+        char buf[64];
+        snprintf(buf, sizeof(buf), ".ev%03d.", ev);
+        stringstream ss;
+        ss << "EVENT " << ev << " " << kind << " " << isw << " " << center;
+        if (evlog)
+            evlog->push_back(ss.str());
+        ev++;
+        return prefix + buf + kind;
+    }
 };
+
+// a key that identifies an operator across tensors and fixtures: hash of its printed name (e.g. "R[ 3 ]", "H")
+template <typename S> static uint64_t op_key(const shared_ptr<OpExpr<S>> &x) {
+    stringstream ss;
+    ss << abs_value(x);
+    return (uint64_t)std::hash<string>()(ss.str());
+}
 
 
 // ---- named-array container (B2XARR01) for effective-Hamiltonian level fixtures ------------------------
@@ -71,6 +99,14 @@ struct ArrayFile {
     void i64(const string &n, const vector<int64_t> &v) { put(n, 1, 8, v.data(), v.size()); }
     void f64(const string &n, const vector<double> &v) { put(n, 2, 8, v.data(), v.size()); }
     void f64(const string &n, const double *p, size_t c) { put(n, 2, 8, p, c); }
+    // bulk data a chain replay computes itself: written as an empty array in chain mode (the length goes to "<name>.len")
+    bool lite = false;
+    void bulk(const string &n, const double *p, size_t c) {
+        const uint64_t cc = c;
+        put(n + ".len", 0, 8, &cc, 1);
+        put(n, 2, 8, p, lite ? 0 : c);
+    }
+    void bulk(const string &n, const vector<double> &v) { bulk(n, v.data(), v.size()); }
     void u32(const string &n, const vector<uint32_t> &v) { put(n, 3, 4, v.data(), v.size()); }
     void u8(const string &n, const vector<uint8_t> &v) { put(n, 4, 1, v.data(), v.size()); }
 };
@@ -132,6 +168,16 @@ template <typename S> struct EhamDump {
         vector<shared_ptr<OpExpr<S>>> order;
         vector<int64_t> iid, has;
         vector<double> fac;
+        vector<uint64_t> keys;
+        string names; // (printed names, one per line: for people reading a fixture)
+        for (auto &kv : t->ops) {
+            keys.push_back(op_key<S>(kv.first));
+            stringstream ss;
+            ss << abs_value(kv.first);
+            names += ss.str() + "\n";
+        }
+        af.u64(pre + ".key", keys);
+        af.put(pre + ".names", 4, 1, names.data(), names.size());
         for (auto &kv : t->ops) {
             order.push_back(kv.first);
             iid.push_back(info_id(kv.second->info, with_cinfo));
@@ -214,9 +260,13 @@ template <typename S> struct CapTF : TensorFunctions<S, double> {
 template <typename S> struct RotTF : TensorFunctions<S, double> {
     typedef double FL;
     DMRG<S, FL, FL> *dmrg = nullptr;
+    MovingEnvironment<S, FL, FL> *me = nullptr; // (chain mode: the initial environments are built before a DMRG exists)
     const DumpSpec *spec = nullptr;
     mutable vector<string> *log = nullptr;
     RotTF(const shared_ptr<OperatorFunctions<S, FL>> &opf) : TensorFunctions<S, FL>(opf) {}
+    bool in_chain() const { return spec != nullptr && spec->lite() && (dmrg == nullptr || dmrg->isweep <= spec->chain); }
+    int cur_sweep() const { return dmrg == nullptr ? -1 : dmrg->isweep; }
+    int cur_center() const { return dmrg != nullptr ? dmrg->me->center : (me != nullptr ? me->center : -1); }
     void left_rotate(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<SparseMatrix<S, FL>> &mpst_bra,
                      const shared_ptr<SparseMatrix<S, FL>> &mpst_ket, shared_ptr<OperatorTensor<S, FL>> &c) const override {
         TensorFunctions<S, FL>::left_rotate(a, mpst_bra, mpst_ket, c);
@@ -239,6 +289,92 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
                         OpNamesSet delayed = OpNamesSet()) const override {
         TensorFunctions<S, FL>::right_contract(a, b, c, cexprs, delayed);
         capture_blocking(a, b, c, cexprs, delayed, true);
+    }
+    // NC -> CN switch of the conventional MPO near the middle site: new (complementary) operators are linear combinations
+    // of operators of the same block, new += factor * op or its transpose (TensorFunctions::numerical_transform,
+    // src/core/tensor_functions.hpp:2462-2517 -> OperatorFunctions::iadd, operator_functions.hpp:135-174)
+    void numerical_transform(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<Symbolic<S>> &names,
+                             const shared_ptr<Symbolic<S>> &exprs) const override {
+        if (in_chain()) { // (written BEFORE the transform runs: the tensor's layout at this point is what a replay has)
+            const bool right = a->lmat == nullptr;
+            EhamDump<S> ed(spec->next_event(right ? "rntr" : "lntr", cur_sweep(), cur_center()) + ".entr");
+            vector<const double *> ptrs;
+            auto order = ed.put_tensor("t", a, false, ptrs);
+            Packed2 T;
+            T.build(ed.ranges);
+            vector<int64_t> off, nop, tb, top, tcj;
+            vector<double> tf;
+            for (auto p : ptrs) {
+                uint64_t o = 0;
+                off.push_back(p != nullptr && T.resolve(p, o) ? (int64_t)o : -1);
+            }
+            for (size_t k = 0; k < names->data.size(); k++) {
+                if (exprs->data[k]->get_type() == OpTypes::Zero)
+                    continue;
+                auto expr = exprs->data[k] * (1.0 / dynamic_pointer_cast<OpElement<S, FL>>(names->data[k])->factor);
+                if (expr->get_type() != OpTypes::Sum)
+                    continue;
+                nop.push_back(EhamDump<S>::find_op(a, order, abs_value(names->data[k])));
+                tb.push_back((int64_t)top.size());
+                for (auto &x : dynamic_pointer_cast<OpSum<S, FL>>(expr)->strings) {
+                    top.push_back(EhamDump<S>::find_op(a, order, x->get_op()));
+                    tf.push_back(x->factor), tcj.push_back(x->conj != 0);
+                }
+            }
+            tb.push_back((int64_t)top.size());
+            ed.af.i64("t.off", off), ed.af.i64("new.op", nop), ed.af.i64("new.term_begin", tb);
+            ed.af.i64("term.op", top), ed.af.f64("term.factor", tf), ed.af.i64("term.conj", tcj);
+            ed.af.u64("meta", vector<uint64_t>{(uint64_t)(cur_sweep() + 1), (uint64_t)cur_center(), (uint64_t)right, T.tot});
+        }
+        TensorFunctions<S, FL>::numerical_transform(a, names, exprs);
+    }
+    // intermediates of the NEXT blocking, formed right after a rotation (moving_environment.hpp:415, 643): operator sums
+    // TEMP = sum_k factor_k * op_k (or its transpose) of the rotated block (TensorFunctions::intermediates,
+    // src/core/tensor_functions.hpp:2404-2459); written in the format of the numerical transform
+    void intermediates(const shared_ptr<Symbolic<S>> &names, const shared_ptr<Symbolic<S>> &exprs,
+                       const shared_ptr<OperatorTensor<S, FL>> &a, bool left) const override {
+        vector<shared_ptr<OpSumProd<S, FL>>> made;
+        if (in_chain()) { // which sums the call below creates (same selection as the reference's loop)
+            auto seen = a->ops;
+            for (size_t i = 0; i < exprs->data.size(); i++)
+                if (exprs->data[i] != nullptr && exprs->data[i]->get_type() == OpTypes::Sum)
+                    for (auto &x : dynamic_pointer_cast<OpSum<S, FL>>(exprs->data[i])->strings)
+                        if (x->get_type() == OpTypes::SumProd) {
+                            auto ex = dynamic_pointer_cast<OpSumProd<S, FL>>(x);
+                            if ((left && ex->b == nullptr) || (!left && ex->a == nullptr) || ex->c == nullptr)
+                                continue;
+                            if (seen.count(ex->c) != 0)
+                                continue;
+                            seen[ex->c] = nullptr;
+                            made.push_back(ex);
+                        }
+        }
+        TensorFunctions<S, FL>::intermediates(names, exprs, a, left);
+        if (!in_chain() || made.empty())
+            return;
+        EhamDump<S> ed(spec->next_event(left ? "lint" : "rint", cur_sweep(), cur_center()) + ".entr");
+        vector<const double *> ptrs;
+        auto order = ed.put_tensor("t", a, false, ptrs);
+        Packed2 T;
+        T.build(ed.ranges);
+        vector<int64_t> off, nop, tb, top, tcj;
+        vector<double> tf;
+        for (auto p : ptrs) {
+            uint64_t o = 0;
+            off.push_back(p != nullptr && T.resolve(p, o) ? (int64_t)o : -1);
+        }
+        for (auto &ex : made) {
+            nop.push_back(EhamDump<S>::find_op(a, order, ex->c));
+            tb.push_back((int64_t)top.size());
+            for (size_t k = 0; k < ex->ops.size(); k++) {
+                top.push_back(EhamDump<S>::find_op(a, order, abs_value((shared_ptr<OpExpr<S>>)ex->ops[k])));
+                tf.push_back(ex->ops[k]->factor), tcj.push_back(ex->conjs[k] ? 1 : 0);
+            }
+        }
+        tb.push_back((int64_t)top.size());
+        ed.af.i64("t.off", off), ed.af.i64("new.op", nop), ed.af.i64("new.term_begin", tb);
+        ed.af.i64("term.op", top), ed.af.f64("term.factor", tf), ed.af.i64("term.conj", tcj);
+        ed.af.u64("meta", vector<uint64_t>{(uint64_t)(cur_sweep() + 1), (uint64_t)cur_center(), (uint64_t)!left, T.tot});
     }
     struct Packed2 {
         vector<const double *> starts;
@@ -273,13 +409,49 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
     void capture_blocking(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<OperatorTensor<S, FL>> &b,
                           const shared_ptr<OperatorTensor<S, FL>> &c, const shared_ptr<Symbolic<S>> &cexprs,
                           OpNamesSet delayed, bool right) const {
-        if (dmrg == nullptr || spec == nullptr || a == nullptr || !delayed.empty())
+        const bool chain = in_chain();
+        if (chain && !delayed.empty()) {
+            cerr << "chain capture needs nodelay=1 (delayed contraction leaves enlarged blocks uncontracted)" << endl;
+            abort();
+        }
+        if (chain && a == nullptr) { // the first block of a chain: c = the site operators (left_assign / right_assign)
+            EhamDump<S> ed(spec->next_event(right ? "rasg" : "lasg", cur_sweep(), cur_center()) + ".easg");
+            vector<const double *> bp;
+            ed.put_tensor("b", b, false, bp);
+            Packed2 Sx, V;
+            vector<pair<const double *, size_t>> sr, vr;
+            for (auto &kv : b->ops)
+                if (kv.second->data != nullptr)
+                    sr.push_back(make_pair((const double *)kv.second->data, (size_t)kv.second->total_memory));
+            vector<uint64_t> ck;
+            vector<int64_t> ci, co, bo;
+            for (auto &kv : c->ops)
+                if (kv.second->data != nullptr)
+                    vr.push_back(make_pair((const double *)kv.second->data, (size_t)kv.second->total_memory));
+            Sx.build(sr), V.build(vr);
+            for (auto p : bp) {
+                uint64_t off = 0;
+                bo.push_back(p != nullptr && Sx.resolve(p, off) ? (int64_t)off : -1);
+            }
+            for (auto &kv : c->ops) {
+                uint64_t off = 0;
+                ck.push_back(op_key<S>(kv.first)), ci.push_back(ed.info_id(kv.second->info, false));
+                co.push_back(kv.second->data != nullptr && V.resolve(kv.second->data, off) ? (int64_t)off : -1);
+            }
+            ed.af.i64("b.off", bo), ed.af.u64("c.key", ck), ed.af.i64("c.info", ci), ed.af.i64("c.off", co);
+            ed.af.u64("meta", vector<uint64_t>{(uint64_t)(cur_sweep() + 1), (uint64_t)cur_center(), (uint64_t)right, Sx.tot, V.tot});
+            ed.af.f64("site", Sx.gather());
             return;
-        pair<int, int> key(dmrg->isweep, dmrg->me->center);
-        const bool with_data = spec->blk.count(key), sym = spec->eblk.count(key);
+        }
+        if (!chain && (dmrg == nullptr || a == nullptr || !delayed.empty()))
+            return;
+        if (spec == nullptr)
+            return;
+        pair<int, int> key(cur_sweep(), cur_center());
+        const bool with_data = !chain && spec->blk.count(key), sym = chain || spec->eblk.count(key);
         if (!with_data && !spec->blk_struct.count(key) && !sym)
             return;
-        {
+        if (!chain) {
             static set<string> done; // first call per (sweep, center, side) only
             stringstream id;
             id << key.first << ":" << key.second << ":" << right;
@@ -306,7 +478,9 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
             if (!seen.insert(cm.get()).second)
                 continue;
             auto expr = exprs->data[i] * (1.0 / cop->factor);
-            if (right)
+            if (chain) // (only the symbolic level is written: nothing to record)
+                ;
+            else if (right)
                 tf_cap->tensor_product(expr, b->ops, a->ops, cm);
             else
                 tf_cap->tensor_product(expr, a->ops, b->ops, cm);
@@ -326,7 +500,10 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
         X.build(xr), Sx.build(sr), V.build(vr);
         auto b0 = opf_cap->seq->batch[0], b1 = opf_cap->seq->batch[1];
         stringstream fn;
-        fn << spec->prefix << ".sw" << key.first << ".c" << key.second << (right ? ".rblk" : ".lblk");
+        if (chain)
+            fn << spec->next_event(right ? "rblk" : "lblk", key.first, key.second);
+        else
+            fn << spec->prefix << ".sw" << key.first << ".c" << key.second << (right ? ".rblk" : ".lblk");
         if (b0->c.size() != 0) {
             cerr << "BLK " << fn.str() << " skipped: two-stage records present" << endl;
             return;
@@ -336,7 +513,7 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
         vector<b2x_outer_term> terms;
         bool ok = true;
         uint64_t n_members = 0;
-        for (size_t g = 0; g < b1->gp.size() && ok; g++) {
+        for (size_t g = 0; g < b1->gp.size() && ok && !chain; g++) {
             const size_t kz = b1->acc_gp[g], gc = b1->gp[g];
             ok = b1->n[g] == 1 && b1->k[g] == 1 && b1->beta[g] == 1.0 && b1->ta[g] == CblasNoTrans;
             n_members += gc;
@@ -393,10 +570,12 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
                 k = e;
             }
         }
-        if (!ok) {
-            cerr << "BLK " << fn.str() << " skipped: record outside the operator ranges (temporaries)" << endl;
+        if (!ok) { // (operator sums formed in temporaries: no record-level list; the symbolic level below still applies)
+            cerr << "BLK " << fn.str() << ": record outside the operator ranges (temporaries), record-level list skipped" << endl;
             opf_cap->seq->clear();
-            return;
+            if (!sym)
+                return;
+            terms.clear();
         }
         for (auto &t : terms) {
             if (t.a_src == 0)
@@ -410,6 +589,7 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
             // (the enlarged ones with their tensor-product connection info) and the data
             EhamDump<S> ed(fn.str() + ".eblk");
             ArrayFile &af = ed.af;
+            af.lite = chain;
             const auto &lt = right ? b : a, &rt = right ? a : b; // (lop, rop) as tensor_product receives them
             vector<const double *> lp, rp;
             auto lorder = ed.put_tensor("lop", lt, false, lp), rorder = ed.put_tensor("rop", rt, false, rp);
@@ -426,6 +606,7 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
             };
             af.i64("lop.off", offs_in(lp, !right)), af.i64("rop.off", offs_in(rp, right));
             vector<int64_t> c_info, c_off, t_begin, ty, cj, ta, tb;
+            vector<uint64_t> c_key;
             vector<double> tf;
             bool supported = true;
             set<const void *> seen2;
@@ -443,7 +624,20 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
                     const bool inter = op->c != nullptr && ((op->b == nullptr && rt->ops.count(op->c)) ||
                                                             (op->a == nullptr && lt->ops.count(op->c)));
                     if (!inter) {
-                        supported = false;
+                        // no stored intermediate: the reference sums the operators into a temporary (iadd with the
+                        // member's factor and transposition flag, tensor_functions.hpp:2236-2261) and takes ONE product;
+                        // by linearity that is the sum of the members' products, which is what is written here
+                        for (size_t k = 0; k < op->ops.size(); k++) {
+                            auto ok = abs_value((shared_ptr<OpExpr<S>>)op->ops[k]);
+                            ty.push_back(0), tf.push_back(op->factor * op->ops[k]->factor);
+                            if (op->b == nullptr) {
+                                cj.push_back(op->conj ^ (op->conjs[k] ? 2 : 0));
+                                ta.push_back(EhamDump<S>::find_op(lt, lorder, op->a)), tb.push_back(EhamDump<S>::find_op(rt, rorder, ok));
+                            } else {
+                                cj.push_back(op->conj ^ (op->conjs[k] ? 1 : 0));
+                                ta.push_back(EhamDump<S>::find_op(lt, lorder, ok)), tb.push_back(EhamDump<S>::find_op(rt, rorder, op->b));
+                            }
+                        }
                         return;
                     }
                     ty.push_back(1), cj.push_back(op->conj), tf.push_back(op->factor);
@@ -466,19 +660,20 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
                 if (cm->total_memory)
                     V.resolve(cm->data, off);
                 c_info.push_back(ed.info_id(cm->info, true)), c_off.push_back((int64_t)off);
+                c_key.push_back(op_key<S>(c->ops.find(abs_value(names[i]))->first));
                 t_begin.push_back((int64_t)ty.size());
                 flat(exprs->data[i] * (1.0 / cop->factor));
             }
             t_begin.push_back((int64_t)ty.size());
-            af.i64("c.info", c_info), af.i64("c.off", c_off), af.i64("c.term_begin", t_begin);
+            af.i64("c.info", c_info), af.i64("c.off", c_off), af.i64("c.term_begin", t_begin), af.u64("c.key", c_key);
             af.i64("term.type", ty), af.i64("term.conj", cj), af.f64("term.factor", tf), af.i64("term.a", ta), af.i64("term.b", tb);
             af.u64("meta", vector<uint64_t>{(uint64_t)key.first, (uint64_t)key.second, (uint64_t)right, (uint64_t)supported,
                                             (uint64_t)terms.size(), X.tot, Sx.tot, V.tot});
-            af.f64("x", X.gather()), af.f64("site", Sx.gather()), af.f64("v_ref", V.gather());
+            af.bulk("x", X.gather()), af.f64("site", Sx.gather()), af.bulk("v_ref", V.gather());
             cerr << "EBLK " << fn.str() << ".eblk ops=" << c_info.size() << " terms=" << ty.size()
                  << " supported=" << supported << endl;
         }
-        if (with_data || spec->blk_struct.count(key)) {
+        if (ok && (with_data || spec->blk_struct.count(key))) {
             ArrayFile af(fn.str() + ".blk");
             af.put("terms", 4, 1, terms.data(), terms.size() * sizeof(b2x_outer_term));
             af.u64("lens", vector<uint64_t>{(uint64_t)terms.size(), Sx.tot, X.tot, V.tot, (uint64_t)right, n_members,
@@ -497,10 +692,11 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
     void maybe_capture(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<SparseMatrix<S, FL>> &bra,
                        const shared_ptr<SparseMatrix<S, FL>> &ket, const shared_ptr<OperatorTensor<S, FL>> &c,
                        bool right) const {
-        if (dmrg == nullptr || spec == nullptr)
+        const bool chain = in_chain();
+        if (spec == nullptr || (!chain && dmrg == nullptr))
             return;
-        pair<int, int> key(dmrg->isweep, dmrg->me->center);
-        bool wd = spec->rot.count(key), st = spec->rot_struct.count(key), er = spec->erot.count(key);
+        pair<int, int> key(cur_sweep(), cur_center());
+        bool wd = !chain && spec->rot.count(key), st = !chain && spec->rot_struct.count(key), er = chain || spec->erot.count(key);
         if (!wd && !st && !er)
             return;
         // record with the reference's tensor_rotate into a private Auto-mode sequence (nothing is executed)
@@ -565,10 +761,15 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
         }
         if (er) { // symbolic-level fixture: what OperatorFunctions::tensor_rotate consumes (infos) and produces
             stringstream efn;
-            efn << spec->prefix << ".sw" << key.first << ".c" << key.second << (right ? ".rrot" : ".lrot") << ".erot";
+            if (chain)
+                efn << spec->next_event(right ? "rrot" : "lrot", key.first, key.second) << ".erot";
+            else
+                efn << spec->prefix << ".sw" << key.first << ".c" << key.second << (right ? ".rrot" : ".lrot") << ".erot";
             EhamDump<S> ed(efn.str());
             ArrayFile &af = ed.af;
+            af.lite = chain;
             vector<int64_t> ai, ci, ao, co;
+            vector<uint64_t> akey, ckey;
             vector<double> afac;
             for (size_t i = 0; i < names.size(); i++)
                 if (names[i]->get_type() != OpTypes::Zero) {
@@ -578,14 +779,28 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
                     ao.push_back(am->total_memory ? (int64_t)X.resolve(am->data) : 0);
                     co.push_back(cm->total_memory ? (int64_t)V.resolve(cm->data) : 0);
                     afac.push_back(am->factor);
+                    // (each tensor's own key objects: equal operators may print differently in different tensors)
+                    akey.push_back(op_key<S>(a->ops.find(pa)->first)), ckey.push_back(op_key<S>(c->ops.find(pa)->first));
                 }
             af.i64("a.info", ai), af.i64("c.info", ci), af.i64("a.off", ao), af.i64("c.off", co), af.f64("a.factor", afac);
+            af.u64("a.key", akey), af.u64("c.key", ckey);
+            if (chain) { // the whole rotated tensor as the next step will see it (operators the rotation does not write included)
+                vector<const double *> cp;
+                ed.put_tensor("ct", c, false, cp);
+            }
             af.i64("mps.info", vector<int64_t>{ed.info_id(bra->info, false), ed.info_id(ket->info, false)});
             af.i64("mps.off", vector<int64_t>{(int64_t)A.resolve(bra->data), (int64_t)A.resolve(ket->data)});
             af.f64("mps.factor", vector<double>{bra->factor, ket->factor});
             af.u64("meta", vector<uint64_t>{(uint64_t)key.first, (uint64_t)key.second, (uint64_t)right, (uint64_t)n, macs,
                                             X.tot, V.tot, A.tot});
-            af.f64("x", X.gather()), af.f64("arena", A.gather()), af.f64("v_ref", V.gather());
+            // (the MPS tensor is data of the starting state while the initial environments are built; later the replay
+            //  rotates with the tensors it obtained from its own decomposition)
+            af.bulk("x", X.gather());
+            if (chain && dmrg != nullptr)
+                af.bulk("arena", A.gather());
+            else
+                af.f64("arena", A.gather());
+            af.bulk("v_ref", V.gather());
             cerr << "EROT " << efn.str() << " ops=" << ai.size() << endl;
         }
         if (!wd && !st)
@@ -640,6 +855,13 @@ template <typename S> struct Dumper : CallbackKernel {
                 capture(isw, site, wd);
             if (spec.eham.count(key))
                 capture_eham(isw, site);
+            if (spec.lite() && isw <= spec.chain) { // chain mode: infos, tensors (keys), expression; no bulk data
+                EhamDump<S> ed(spec.next_event("eham", isw, site) + ".eham");
+                ed.af.lite = true;
+                write_eham_common(ed, dmrg->current_eff_ham);
+                ed.af.u64("chain.meta", vector<uint64_t>{(uint64_t)isw, (uint64_t)site, (uint64_t)dmrg->me->n_sites,
+                                                         (uint64_t)((isw % 2 == 0) == start_forward)});
+            }
             if (stop_after == key) { // structure captures at large M: the rest of the sweep is not needed
                 ofstream lf((spec.prefix + ".log").c_str());
                 for (auto &l : log)
@@ -712,7 +934,7 @@ template <typename S> struct Dumper : CallbackKernel {
         vector<double> arena(tot);
         for (size_t i = 0; i < rg.size(); i++)
             memcpy(arena.data() + offs[i], rg[i].first, rg[i].second * 8);
-        af.f64("arena", arena);
+        af.bulk("arena", arena);
         auto offs_of = [&](const vector<const double *> &ptrs) {
             vector<int64_t> o;
             for (auto p : ptrs) {
@@ -1111,10 +1333,20 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     mps_info->save_mutable();
     mps_info->deallocate_mutable();
     auto me = make_shared<MovingEnvironment<S, FL, FL>>(mpo, mps, mps, "DMRG");
+    auto dumper = make_shared<Dumper<S>>();
+    dumper->spec.prefix = prefix + rank_tag;
+    shared_ptr<RotTF<S>> rtf;
+    if (kv.count("chain")) { // every blocking / rotation from the very first one: hook in before the environments exist
+        dumper->spec.chain = Parsing::to_int(kv["chain"]);
+        dumper->spec.evlog = &dumper->log;
+        rtf = make_shared<RotTF<S>>(mpo->tf->opf);
+        rtf->me = me.get(), rtf->spec = &dumper->spec, rtf->log = &dumper->log;
+        mpo->tf = rtf;
+    }
     me->init_environments(false);
-    if (para_rule == nullptr) // (the reference's sum-MPO test keeps the default: no delayed contraction)
+    if (para_rule == nullptr && !kv.count("nodelay")) // (the reference's sum-MPO test keeps the default: no delayed contraction)
         me->delayed_contraction = OpNamesSet::normal_ops();
-    me->cached_contraction = true;
+    me->cached_contraction = !kv.count("nocache");
     vector<ubond_t> bdims = {(ubond_t)M};
     vector<double> noises = {1E-8, 1E-9, 0.0};
     if (kv.count("noise")) {
@@ -1127,10 +1359,10 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     dmrg->noise_type = NoiseTypes::ReducedPerturbative;
     dmrg->decomp_type = DecompositionTypes::DensityMatrix;
     dmrg->davidson_soft_max_iter = kv.count("dav_iter") ? Parsing::to_int(kv["dav_iter"]) : 4000;
-    auto dumper = make_shared<Dumper<S>>();
     dumper->dmrg = dmrg.get();
-    dumper->spec.prefix = prefix + rank_tag;
     dumper->start_forward = mps->center == 0;
+    if (rtf != nullptr)
+        rtf->dmrg = dmrg.get();
     if (kv.count("stop_after"))
         dumper->stop_after = *parse_pairs(kv["stop_after"]).begin();
     if (kv.count("dump"))
@@ -1157,9 +1389,10 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
         dumper->spec.blk_struct = parse_pairs(kv["blk_struct"]);
     if (kv.count("eblk"))
         dumper->spec.eblk = parse_pairs(kv["eblk"]);
-    if (!dumper->spec.rot.empty() || !dumper->spec.rot_struct.empty() || !dumper->spec.erot.empty() ||
-        !dumper->spec.blk.empty() || !dumper->spec.blk_struct.empty() || !dumper->spec.eblk.empty()) {
-        auto rtf = make_shared<RotTF<S>>(mpo->tf->opf);
+    if (rtf == nullptr &&
+        (!dumper->spec.rot.empty() || !dumper->spec.rot_struct.empty() || !dumper->spec.erot.empty() ||
+         !dumper->spec.blk.empty() || !dumper->spec.blk_struct.empty() || !dumper->spec.eblk.empty())) {
+        rtf = make_shared<RotTF<S>>(mpo->tf->opf);
         rtf->dmrg = dmrg.get(), rtf->spec = &dumper->spec, rtf->log = &dumper->log;
         mpo->tf = rtf; // MovingEnvironment rotates through mpo->tf (src/dmrg/moving_environment.hpp:360)
     }

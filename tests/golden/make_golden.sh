@@ -59,3 +59,9 @@ $R $D/H10.STO6G.R1.8.FCIDUMP sz 500 2 ./h10m500 struct=1:4 stop_after=1:4 iprint
 # sum-MPO partition: the reference on 2 MPI ranks with ParallelRuleSimple(IJ) (make -C oracle _ref/ref_dump_mpi):
 # every rank's own plan + operators, psi, and sigma_ref = the ALL-REDUCED H psi; *.prefactors = index_prefactor tables
 /opt/conda/bin/mpirun -n 2 ../../oracle/_ref/ref_dump_mpi $D/N2.STO3G.FCIDUMP su2 200 6 ./n2su2_ij para=ij prefactors=1 dump=1:5,2:4 nthreads=4 iprint=0
+# the site-to-site chain (tests/test_sweep_gpu.py): every blocking / rotation / operator-sum / effective-Hamiltonian event
+# of the initial environments and of sweeps 0 and 1 of N2/STO-3G SU2 M=200 at the symbolic level, in call order, without
+# operator or wavefunction data (delayed contraction and the contraction cache off: every enlarged block is contracted in
+# full; no noise, tight Davidson, so that the site energies are a deterministic function of the chain)
+mkdir -p chain_n2su2
+$R $D/N2.STO3G.FCIDUMP su2 200 2 ./chain_n2su2/n2c chain=1 nodelay=1 nocache=1 noise=0,0 tol=1e-12 iprint=0

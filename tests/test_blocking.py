@@ -160,7 +160,7 @@ def test_host_mirror_records_block_products(built):
     assert seq.n_outer == 2 + 24 and seq.outer_dims()[2] == (2, 3, 3, 1, 0, 0, 18, 1.0)
     seq.iadd((out, 500, 4, 6), a, 0.25)
     seq.iadd((out, 600, 6, 4), a, 0.25, True)
-    assert seq.outer_dims()[-2:] == [(1, 24, 0, 1, 0, 0, 24, 0.25), (6, 4, 1, 6, 0, 0, 4, 0.25)]
+    assert seq.outer_dims()[-2:] == [(4, 6, 6, 1, 0, 0, 6, 0.25), (6, 4, 1, 6, 0, 0, 4, 0.25)]
     with pytest.raises(RuntimeError):
         seq.iadd((out, 500, 4, 6), a, 1.0, False, 0.0)
     seq.clear()
