@@ -73,6 +73,9 @@ def parse():
     ap.add_argument("--cpu-gmac", type=float, default=0.0, help="MAC budget of the cpu_baseline sample (0 = auto)")
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed replays of the cpu_baseline sample (after one warm-up)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--site-step", type=int, default=-1,
+                    help="1: also time the other device steps of a site (noise, rotation, blocking) at this bond dimension; "
+                         "default: on for the one-GPU Cr2 workloads up to M=4000")
     ap.add_argument("--tile-n", type=int, default=0)
     ap.add_argument("--item-macs", type=int, default=0)
     ap.add_argument("--tile-m", type=int, default=0, help="tallest sector kept on the fused wave kernel (0 = default)")
@@ -161,6 +164,95 @@ def cpu_baseline(plan_pairs, psi_len, sigma_len, budget_macs, reps, log):
             len(sel), macs / 1e9, alen * 8 / 1e9, reps, med, best, cores,
             "block2 BatchGEMMSeq Tasked + MKL dgemm" if use_ref else "oracle/hpsi_oracle.c OpenMP loops"),
     }
+
+
+def site_step(scale, M, hpsi_ms, compile_s, dev, log):
+    """The other device steps of ONE site of a two-site sweep at the bond dimension of the workload, each timed on its own
+    with the structures the reference recorded at the same Cr2/SVP site (M=250, sweep 1, site / center 20) scaled like the
+    H.psi plan: the perturbative-noise GEMM list, the rotation of the enlarged block (a pair plan), the blocking (an
+    element-wise list; synthetic blocks with the element count of the captured list x scale^2, because that list is
+    not scaled exactly).  Returns the `site_step_ms` object: what a site costs besides Ndav x H.psi."""
+    import torch
+
+    from block2_preview_amd import capi, synth
+    from block2_preview_amd.planfile import OUTER_TERM_DTYPE, read_gemm_list, read_outer_struct_npz, read_struct_npz
+
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {"M": M, "hpsi_ms": round(hpsi_ms, 3), "hpsi_plan_compile_ms": round(compile_s * 1e3, 1)}
+
+    def timed(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
+    # perturbative noise (once per site while the noise is on)
+    gl = synth.scale_gemm_list(read_gemm_list(os.path.join(GOLD, "cr2_su2_m250_sw1_site20.pnoise_struct.npz")), scale)
+    arena_t = torch.rand(gl.arena_len, dtype=torch.float64, device=dev)
+    vin = torch.rand(gl.in_len, dtype=torch.float64, device=dev)
+    vout = torch.zeros(gl.out_len, dtype=torch.float64, device=dev)
+    arena = capi.Arena.adopt_device(arena_t.data_ptr(), gl.arena_len, keep=arena_t)
+    t0 = time.perf_counter()
+    plan = capi.GemmPlan(arena, gl.gemms, gl.in_len, gl.out_len)
+    out["noise_compile_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    out["noise_ms"] = round(timed(lambda: plan.execute_device(vin.data_ptr(), vout.data_ptr(), 1.0, stream)), 3)
+    out["noise_operator_gb"] = round(gl.arena_len * 8 / 1e9, 2)
+    plan.close(), arena.close()
+    del arena_t, vin, vout
+    torch.cuda.empty_cache()
+    # rotation of the enlarged block into the truncated basis (once per site)
+    rp = synth.scale_plan(read_struct_npz(os.path.join(GOLD, "cr2_su2_m250_sw1_c20_rrot.rotstruct.npz")), scale)
+    arena_t = torch.rand(rp.arena_len, dtype=torch.float64, device=dev)  # the MPS tensor
+    x = torch.rand(rp.psi_len, dtype=torch.float64, device=dev)           # the enlarged operators
+    v = torch.zeros(rp.sigma_len, dtype=torch.float64, device=dev)        # the rotated operators
+    arena = capi.Arena.adopt_device(arena_t.data_ptr(), rp.arena_len, keep=arena_t)
+    t0 = time.perf_counter()
+    plan = capi.Plan(arena, rp.pairs, rp.psi_len, rp.sigma_len)
+    out["rotate_compile_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
+    out["rotate_ms"] = round(timed(lambda: plan.execute_device(x.data_ptr(), v.data_ptr(), 1.0, stream)), 3)
+    out["rotate_enlarged_gb"] = round(rp.psi_len * 8 / 1e9, 2)
+    plan.close(), arena.close()
+    del arena_t, x, v
+    torch.cuda.empty_cache()
+    # blocking: block (x) scalar site operator terms, synthetic blocks carrying the captured list's element counts
+    t, lens = read_outer_struct_npz(os.path.join(GOLD, "cr2_su2_m250_sw1_c20_rblk.blkstruct.npz"))
+    term_elems = int((t["m"].astype(np.int64) * t["n"]).sum()) * scale * scale
+    out_elems = int(lens[3]) * scale * scale
+    b = 16 * scale  # block edge (the captured blocks are 8-30 wide at M=250)
+    g = 3
+    n_sec = max(1, out_elems // (g * b) ** 2)
+    per_sub = max(1, round(term_elems / (n_sec * g * g * b * b)))
+    n_blocks = 64
+    rows = []
+    rng = np.random.default_rng(0)
+    for s_ in range(n_sec):
+        for i in range(g):
+            for j in range(g):
+                for k in range(per_sub):
+                    tr = k % 6 == 5  # a sixth of the captured terms read their block transposed
+                    rows.append((b, b, 1 if tr else b, b if tr else 1, 0, 0, g * b, 1, 0, (0, 0), 0.5 + k,
+                                 int(rng.integers(n_blocks)) * b * b, int(rng.integers(16)),
+                                 s_ * (g * b) ** 2 + i * b * g * b + j * b))
+    terms = np.array(rows, OUTER_TERM_DTYPE)
+    arena_t = torch.rand(16, dtype=torch.float64, device=dev)
+    vin = torch.rand(n_blocks * b * b, dtype=torch.float64, device=dev)
+    vout = torch.zeros(n_sec * (g * b) ** 2, dtype=torch.float64, device=dev)
+    arena = capi.Arena.adopt_device(arena_t.data_ptr(), 16, keep=arena_t)
+    out["block_ms"] = round(timed(lambda: capi.outer_build(arena, terms, vin.data_ptr(), vout.data_ptr(), True,
+                                                           len(vin), len(vout), stream)), 3)
+    out["block_note"] = "synthetic: %d sectors of %dx%d blocks of %d^2, %d terms per block (%.2f G term elements, %.2f G outputs as the captured list x%d^2); includes the host compile of the list" % (
+        n_sec, g, g, b, per_sub, len(terms) * b * b / 1e9, len(vout) / 1e9, scale)
+    arena.close()
+    del arena_t, vin, vout
+    torch.cuda.empty_cache()
+    out["site_ms_ndav10"] = round(10 * hpsi_ms + out["noise_ms"] + out["rotate_ms"] + out["block_ms"]
+                                  + out["hpsi_plan_compile_ms"] + out["noise_compile_ms"] + out["rotate_compile_ms"], 1)
+    out["note"] = ("one site = plan compile + Ndav x H.psi + noise + rotation + blocking, every operator resident in HBM "
+                   "(no re-upload); site_ms_ndav10 assumes 10 Davidson iterations (the reference needs 5-90 per site)")
+    return out
 
 
 def traffic_of(workload):
@@ -255,6 +347,8 @@ def main():
     psi_t = torch.empty(full.psi_len, dtype=torch.float64, device=dev).uniform_(0.0, 1.0, generator=gp)
     sigma_t = torch.zeros(full.sigma_len, dtype=torch.float64, device=dev)
     arena = capi.Arena.adopt_device(arena_t.data_ptr(), arena_len, keep=arena_t)
+    torch.cuda.synchronize()
+    t0 = time.time()  # plan compile = host segmentation of the pair list + upload of the work lists + scratch allocation
     plan = capi.Plan(arena, mine, full.psi_len, full.sigma_len, tile_n=args.tile_n, item_macs=args.item_macs,
                      scratch_mb=args.scratch_mb, two_stage=args.two_stage, tile_m=args.tile_m, keep_order=args.keep_order)
     st = plan.stats
@@ -326,6 +420,16 @@ def main():
                          "atomic_fallback": st["fallback"]},
             "sigma_checksum": checksum,
         }
+        want_site = args.site_step == 1 or (args.site_step < 0 and world == 1 and args.workload.startswith("cr2_")
+                                            and not args.scale and not args.struct)
+        if want_site:
+            plan.close(), arena.close()  # free the H.psi operators before the other steps' operands are generated
+            del arena_t, psi_t, sigma_t
+            torch.cuda.empty_cache()
+            try:
+                out["site_step_ms"] = site_step(scale, M, dt / args.steps * 1e3, compile_s, dev, log)
+            except Exception as e:  # never lose the bench line over the extra measurement
+                out["site_step_ms"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu:
             # ~1 TMAC of the M=4000 plan (5 s per replay at 200 GMAC/s), never more than the whole plan
             budget = args.cpu_gmac * 1e9 if args.cpu_gmac > 0 else min(float(full.macs), 1.0e12)

@@ -161,6 +161,7 @@ class Arena:
         if self._h is not None:
             lib().b2x_arena_destroy(self._h)
             self._h = None
+        self._keep = None  # (an adopted device buffer is the caller's again)
 
     def __del__(self):
         try:
