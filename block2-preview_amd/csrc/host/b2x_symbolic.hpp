@@ -17,6 +17,7 @@
 // OpExpr tree — the tree belongs to the MPO layer, which is out of scope.  Host-only integer / 9j work; the
 // numerics run on the device through BatchGEMMSeq (b2x_host.hpp).
 #pragma once
+#include "b2x_fpcodec.hpp"
 #include <fstream>
 #include <istream>
 #include <ostream>
@@ -367,8 +368,8 @@ template <typename S> struct SparseMatrix {
     double factor = 1.0;
     size_t total_memory = 0;
     std::vector<double> storage; // owns the data of a matrix loaded from disk
-    // on-disk layout of the reference (src/core/sparse_matrix.hpp:896-971, uncompressed): [info if load_info] factor
-    // (f64), total_memory (size_t), data.  The compressed variant (FPCodec, total_memory == SIZE_MAX flag) is refused.
+    // on-disk layout of the reference (src/core/sparse_matrix.hpp:896-971): [info if load_info] factor (f64),
+    // total_memory (size_t), data; in compressed storage: factor, SIZE_MAX, total_memory, FPCodec array (b2x_fpcodec.hpp)
     void load_data(const std::string &filename, bool load_info = false) {
         std::ifstream ifs(filename.c_str(), std::ios::binary);
         if (!ifs.good())
@@ -379,24 +380,36 @@ template <typename S> struct SparseMatrix {
         }
         uint64_t tm;
         ifs.read((char *)&factor, sizeof(factor)), ifs.read((char *)&tm, sizeof(tm));
-        if (tm == ~(uint64_t)0)
-            throw std::runtime_error("SparseMatrix:load_data on '" + filename + "': compressed storage is not supported");
+        const bool coded = tm == ~(uint64_t)0;
+        if (coded)
+            ifs.read((char *)&tm, sizeof(tm));
         total_memory = (size_t)tm;
         storage.resize(total_memory);
-        ifs.read((char *)storage.data(), (std::streamsize)(total_memory * sizeof(double)));
+        if (coded)
+            FPCodec::read_array(ifs, storage.data(), total_memory);
+        else
+            ifs.read((char *)storage.data(), (std::streamsize)(total_memory * sizeof(double)));
         if (ifs.fail() || ifs.bad())
             throw std::runtime_error("SparseMatrix:load_data on '" + filename + "' failed.");
         data = storage.data();
     }
-    void save_data(const std::string &filename, bool save_info = false) const {
+    // codec != nullptr: compressed storage (frame->compressed_sparse_tensor_storage with frame->fp_codec in the reference)
+    void save_data(const std::string &filename, bool save_info = false, const FPCodec *codec = nullptr) const {
         std::ofstream ofs(filename.c_str(), std::ios::binary);
         if (!ofs.good())
             throw std::runtime_error("SparseMatrix:save_data on '" + filename + "' failed.");
         if (save_info)
             info->save_data(ofs);
         uint64_t tm = total_memory;
-        ofs.write((const char *)&factor, sizeof(factor)), ofs.write((const char *)&tm, sizeof(tm));
-        ofs.write((const char *)data, (std::streamsize)(total_memory * sizeof(double)));
+        const uint64_t flag = ~(uint64_t)0;
+        ofs.write((const char *)&factor, sizeof(factor));
+        if (codec)
+            ofs.write((const char *)&flag, sizeof(flag));
+        ofs.write((const char *)&tm, sizeof(tm));
+        if (codec)
+            codec->write_array(ofs, data, total_memory);
+        else
+            ofs.write((const char *)data, (std::streamsize)(total_memory * sizeof(double)));
         if (!ofs.good())
             throw std::runtime_error("SparseMatrix:save_data on '" + filename + "' failed.");
     }

@@ -7,6 +7,7 @@
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
+#include <sstream>
 
 namespace b2xh {
 namespace py = pybind11;
@@ -472,7 +473,7 @@ template <typename S> py::dict sm_load(const std::string &fn) {
 template <typename S>
 void sm_save(const std::string &fn, const std::vector<uint64_t> &q, const std::vector<uint32_t> &nb,
              const std::vector<uint32_t> &nk, const std::vector<uint32_t> &nt, const std::vector<uint64_t> &meta, double factor,
-             py::array_t<double, py::array::c_style> data) {
+             py::array_t<double, py::array::c_style> data, double fp_prec = 0.0, size_t fp_chunk = 4096) {
     SparseMatrix<S> m;
     m.info = std::make_shared<SparseMatrixInfo<S>>();
     m.info->n = (int)q.size();
@@ -481,7 +482,11 @@ void sm_save(const std::string &fn, const std::vector<uint64_t> &q, const std::v
     m.info->n_states_bra = nb, m.info->n_states_ket = nk, m.info->n_states_total = nt;
     m.info->delta_quantum = S(meta[0]), m.info->is_fermion = meta[1] != 0, m.info->is_wavefunction = meta[2] != 0;
     m.factor = factor, m.total_memory = (size_t)data.size(), m.data = data.mutable_data();
-    m.save_data(fn, true);
+    if (fp_prec > 0.0) {
+        FPCodec codec(fp_prec, fp_chunk);
+        m.save_data(fn, true, &codec);
+    } else
+        m.save_data(fn, true);
 }
 
 inline void bind_symbolic(py::module_ &m) {
@@ -490,11 +495,25 @@ inline void bind_symbolic(py::module_ &m) {
     });
     m.def("sparse_matrix_save", [](const std::string &sym, const std::string &fn, std::vector<uint64_t> q, std::vector<uint32_t> nb,
                                    std::vector<uint32_t> nk, std::vector<uint32_t> nt, std::vector<uint64_t> meta, double factor,
-                                   py::array_t<double, py::array::c_style> data) {
+                                   py::array_t<double, py::array::c_style> data, double fp_prec, size_t fp_chunk) {
         if (sym == "su2")
-            sm_save<SU2>(fn, q, nb, nk, nt, meta, factor, data);
+            sm_save<SU2>(fn, q, nb, nk, nt, meta, factor, data, fp_prec, fp_chunk);
         else
-            sm_save<SZ>(fn, q, nb, nk, nt, meta, factor, data);
+            sm_save<SZ>(fn, q, nb, nk, nt, meta, factor, data, fp_prec, fp_chunk);
+    }, py::arg("sym"), py::arg("filename"), py::arg("quanta"), py::arg("nbra"), py::arg("nket"), py::arg("ntot"), py::arg("meta"),
+       py::arg("factor"), py::arg("data"), py::arg("fp_prec") = 0.0, py::arg("fp_chunk") = (size_t)4096);
+    // FPCodec of the reference's scratch files on plain arrays: encode -> the byte stream write_array produces
+    m.def("fpcodec_encode", [](py::array_t<double, py::array::c_style> a, double prec, size_t chunk) {
+        FPCodec c(prec, chunk);
+        std::ostringstream os;
+        c.write_array(os, a.data(), (size_t)a.size());
+        return py::bytes(os.str());
+    }, py::arg("data"), py::arg("prec"), py::arg("chunk") = (size_t)4096);
+    m.def("fpcodec_decode", [](py::bytes b, size_t len) {
+        std::istringstream is((std::string)b);
+        py::array_t<double> out((py::ssize_t)len);
+        FPCodec::read_array(is, out.mutable_data(), len);
+        return out;
     });
     m.def("symbolic_blocking", [](const std::string &sym, const py::dict &d, bool execute) {
         if (sym == "sz")

@@ -211,3 +211,16 @@ def read_outer_struct_npz(fn):
         if name != "reserved":
             t[name] = z[name]
     return t, z["lens"].copy()
+
+
+def partition_filename(save_dir, prefix_distri, tag, left, i, info=False):
+    """scratch file of a renormalised block (MovingEnvironment::get_left/right_partition_filename,
+    src/dmrg/moving_environment.hpp:857-880): <save_dir>/<prefix_distri>.PART.[INFO.]<tag>.LEFT|RIGHT.<i>; prefix_distri is
+    "F<rank>" under a parallel rule (src/core/parallel_rule.hpp:340), "F0" otherwise"""
+    return "%s/%s.PART.%s%s.%s.%d" % (save_dir, prefix_distri, "INFO." if info else "", tag, "LEFT" if left else "RIGHT", i)
+
+
+def mps_tensor_filename(save_dir, prefix, tag, i):
+    """scratch file of MPS tensor i (MPS::get_filename, src/dmrg/mps.hpp): <save_dir>/<prefix>.MPS.<tag>.<i>; i = -1 holds
+    the canonical form and center"""
+    return "%s/%s.MPS.%s.%d" % (save_dir, prefix, tag, i)

@@ -31,6 +31,7 @@
  *   tensor_file=<i>[,<j>...]                 after the run: MPS tensor i written by the reference's own
  *                                            SparseMatrix::save_data(file, true) (src/core/sparse_matrix.hpp:957-971) next to
  *                                            its content as named arrays (on-disk format fixture)
+ *   fp_prec=<x> [fp_chunk=<n>]               (with tensor_file=) also write the tensor in compressed storage, <file>.fpc
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
  *   prefactors=1                             (with para=) also write ParallelRuleSimple::index_prefactor of every (i,j), (i,j,k,l)
  *   para=i|ij                                sum-MPO parallel rule (ParallelRuleSimple I / IJ); under mpirun with the
@@ -1410,6 +1411,14 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
             auto t = mps->tensors[i];
             string fn = prefix + ".mps" + tok + ".tensor";
             t->save_data(fn, true); // info + factor + total_memory + data, as MPS::save_tensor writes it (mps.hpp:2573-2578)
+            if (kv.count("fp_prec")) { // the same tensor in compressed storage (FPCodec, src/core/fp_codec.hpp:158-)
+                frame_<double>()->fp_codec = make_shared<FPCodec<double>>(Parsing::to_double(kv["fp_prec"]),
+                                                                            kv.count("fp_chunk") ? (size_t)Parsing::to_int(kv["fp_chunk"]) : 1024);
+                frame_<double>()->compressed_sparse_tensor_storage = true;
+                t->save_data(fn + ".fpc", true);
+                frame_<double>()->compressed_sparse_tensor_storage = false;
+                frame_<double>()->fp_codec = nullptr;
+            }
             EhamDump<S> ed(fn + ".arr");
             int id = ed.info_id(t->info, false);
             ed.af.f64("factor", vector<double>{t->factor});

@@ -59,3 +59,81 @@ def test_refuses_bad_files(built, tmp_path):
     bad.write_bytes(open(FILES[0], "rb").read()[:40])
     with pytest.raises(RuntimeError):
         b2x_host.sparse_matrix_load(_sym(FILES[0]), str(bad))
+
+
+# ---- compressed storage (FPCodec, src/core/fp_codec.hpp:158-; SparseMatrix::save_data with
+# frame->compressed_sparse_tensor_storage, src/core/sparse_matrix.hpp:937-957) -----------------------------------------
+FPC = sorted(glob.glob(os.path.join(GOLDEN, "diskc_*.tensor.fpc")))
+FPC_ARGS = {"diskc_n2su2": (1e-8, 64), "diskc_h10sz": (1e-5, 1024)}  # (precision, chunk) the reference wrote them with
+
+
+def _args(fn):
+    return FPC_ARGS[os.path.basename(fn).split(".")[0]]
+
+
+def test_compressed_fixtures_present():
+    assert len(FPC) >= 2
+
+
+@pytest.mark.parametrize("fn", FPC, ids=os.path.basename)
+def test_compressed_file_written_by_the_reference(built, fn, tmp_path):
+    """the reference wrote the same MPS tensor plain (.tensor) and through its FPCodec (.tensor.fpc): the mirror decodes
+    the coded file to the plain values within the precision, and coding the plain values reproduces the reference's coded
+    file byte for byte (the codec is a bit stream: parity is exact)"""
+    from block2_preview_amd import b2x_host
+
+    prec, chunk = _args(fn)
+    raw = b2x_host.sparse_matrix_load(_sym(fn), fn[:-4])
+    dec = b2x_host.sparse_matrix_load(_sym(fn), fn)
+    assert dec["quanta"] == raw["quanta"] and dec["factor"] == raw["factor"] and len(dec["data"]) == len(raw["data"])
+    err = np.abs(np.asarray(dec["data"]) - np.asarray(raw["data"]))
+    assert 0 < err.max() < 2 * prec  # lossy: what lies below 2^(exponent of prec + 1) may be dropped, as in the reference
+    out = str(tmp_path / "re.fpc")
+    b2x_host.sparse_matrix_save(_sym(fn), out, raw["quanta"], raw["nbra"], raw["nket"], raw["ntot"], raw["meta"],
+                                raw["factor"], raw["data"], fp_prec=prec, fp_chunk=chunk)
+    assert open(out, "rb").read() == open(fn, "rb").read()
+    # decoded values survive another pass through the codec unchanged
+    out2 = str(tmp_path / "re2.fpc")
+    b2x_host.sparse_matrix_save(_sym(fn), out2, dec["quanta"], dec["nbra"], dec["nket"], dec["ntot"], dec["meta"],
+                                dec["factor"], dec["data"], fp_prec=prec, fp_chunk=chunk)
+    assert np.array_equal(b2x_host.sparse_matrix_load(_sym(fn), out2)["data"], dec["data"])
+
+
+@pytest.mark.parametrize("prec,chunk,n", [(1e-6, 7, 100), (1e-12, 4096, 5000), (0.5, 16, 33), (1e-3, 1, 3), (1e-9, 64, 0)])
+def test_codec_round_trip_properties(built, prec, chunk, n):
+    """random arrays over many magnitudes (zeros, tiny values, both signs): |x - decode(encode(x))| < 2 prec (a value whose
+    exponent equals that of prec decodes to zero when it is the smallest of its chunk, exactly as in the reference's
+    decoder, fp_codec.hpp:204-206); larger values keep their sign; the coded stream never exceeds one word per element
+    plus one per chunk; decoded values pass through the codec unchanged"""
+    from block2_preview_amd import b2x_host
+
+    rng = np.random.default_rng(int(chunk) + n)
+    x = rng.standard_normal(n) * 10.0 ** rng.integers(-15, 6, n)
+    if n > 4:
+        x[::5] = 0.0
+    blob = b2x_host.fpcodec_encode(x, prec, chunk)
+    y = np.asarray(b2x_host.fpcodec_decode(blob, n))
+    assert len(y) == n
+    if n:
+        assert np.abs(y - x).max() < 2 * prec
+        big = np.abs(x) > 4 * prec
+        assert np.array_equal(np.sign(y[big]), np.sign(x[big]))
+    n_chunks = (n + chunk - 1) // chunk
+    assert len(blob) <= 4 + 8 + 8 * n_chunks + 8 * (n + n_chunks) + 4
+    assert np.array_equal(np.asarray(b2x_host.fpcodec_decode(b2x_host.fpcodec_encode(y, prec, chunk), n)), y)
+
+
+def test_partition_file_names(built):
+    """scratch file names of MovingEnvironment / MPS (src/dmrg/moving_environment.hpp:857-880, src/dmrg/mps.hpp): the names
+    the reference created in its scratch directory during the run that wrote the fixtures"""
+    from block2_preview_amd.planfile import partition_filename, mps_tensor_filename
+
+    assert partition_filename("/tmp/s", "F0", "DMRG", True, 3) == "/tmp/s/F0.PART.DMRG.LEFT.3"
+    assert partition_filename("/tmp/s", "F0", "DMRG", False, 12, info=True) == "/tmp/s/F0.PART.INFO.DMRG.RIGHT.12"
+    assert mps_tensor_filename("/tmp/s", "F", "KET", 5) == "/tmp/s/F.MPS.KET.5"
+    listed = open(os.path.join(GOLDEN, "scratch_listing.txt")).read().split()
+    made = {os.path.basename(partition_filename("/x", "F0", "DMRG", left, i, info)) for left in (True, False)
+            for i in range(10) for info in (True, False)}
+    made |= {os.path.basename(mps_tensor_filename("/x", "F", "KET", i)) for i in range(-1, 10)}
+    parts = [f for f in listed if ".PART." in f or (f.startswith("F.MPS.KET.") )]
+    assert parts and all(f in made for f in parts), [f for f in parts if f not in made]
