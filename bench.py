@@ -55,6 +55,12 @@ WORKLOADS = {
                  "Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20) x2 -> M=500"),
     "cr2_m250": ("cr2_su2_m250_sw1_site20.struct.npz", 1, 250,
                  "Cr2/SVP SU2 mid-chain H.psi plan (reference capture M=250 sw1 site20)"),
+    # the same molecule and site WITHOUT occupation-guided initial bond dimensions (MPSInfo::set_bond_dimension instead of
+    # set_bond_dimension_using_occ): 457 470 pairs, more than half of the MACs in blocks narrower than 8 (SURVEY's counts)
+    "cr2_noocc_m4000": ("cr2_su2_m250_noocc_sw1_site20.struct.npz", 16, 4000,
+                        "Cr2/SVP SU2 mid-chain H.psi plan, uniform initial bond dimensions (reference capture M=250 sw1 site20) x16 -> M=4000"),
+    "cr2_noocc_m1000": ("cr2_su2_m250_noocc_sw1_site20.struct.npz", 4, 1000,
+                        "Cr2/SVP SU2 mid-chain H.psi plan, uniform initial bond dimensions (reference capture M=250 sw1 site20) x4 -> M=1000"),
     "h10_m500": ("h10_sz_m500_sw1_site4.struct.npz", 1, 500,
                  "H10/STO-6G R=1.8 SZ mid-chain H.psi plan, reference capture at M=500 (sw1 site4)"),
     "hubbard_m3000": ("hubbard_l16_u4_sz_m3000_sw0_site7.struct.npz", 1, 3000,
@@ -421,7 +427,7 @@ def main():
             "sigma_checksum": checksum,
         }
         want_site = args.site_step == 1 or (args.site_step < 0 and world == 1 and args.workload.startswith("cr2_")
-                                            and not args.scale and not args.struct)
+                                            and "noocc" not in args.workload and not args.scale and not args.struct)
         if want_site:
             plan.close(), arena.close()  # free the H.psi operators before the other steps' operands are generated
             del arena_t, psi_t, sigma_t

@@ -259,40 +259,68 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
     // buffer needs slack.  (An exact variant of these offsets — last granule fetched one element earlier, B slots and
     // the tile store following it — was measured: +13 % time at M=250, +6 % at M=500, because this per-segment
     // arithmetic IS the bottleneck of short segments; profiles/README.md.)
-    // per-lane offsets of the chunk at k offset kb of segment S: unclamped for a full chunk (valid for every full chunk
-    // of the segment), clamped to the last k for the partial one
+    // Per-lane offsets of the chunk at k offset kb of segment S: unclamped for a full chunk (valid for every full chunk
+    // of the segment), clamped to the last k for the partial one.  This arithmetic runs once or twice per SEGMENT, and for
+    // the short segments of small bond dimensions (one or two chunks of 8-16 MFMAs) it used to cost more vector-ALU time
+    // than the MFMAs themselves (~80 VALU per call + ~50 in a masked commit; the fp64 MFMA pipe and the VALU do not
+    // overlap).  What depends on the lane alone is therefore computed once per ITEM (lane_consts; kept in registers for
+    // tiles up to 64 rows, recomputed for the taller ones whose accumulators leave no room), the k clamp is a scalar
+    // (min with 0xFFFF for a full chunk: no select), products are 24-bit multiply-adds, and the B mask is a bit count.
+    // A 16-byte A granule may reach ONE element behind its operand: a k-contiguous operand whose K is not a multiple of
+    // the chunk depth is read up to element K of every row, a row-contiguous one whose row count is not a multiple of 16
+    // up to row mr of every k.  Inside a buffer that element is the caller's own neighbouring (finite) data and meets a
+    // zeroed B lane; where it would lie OUTSIDE the buffer — the operand ends exactly at the end of an adopted arena or
+    // of psi — the plan compiler hands the kernel a staged copy instead (stage_residual_reads, b2x_plan.cpp), so no
+    // buffer needs slack.  (An exact variant of these offsets — last granule fetched one element earlier, B slots and
+    // the tile store following it — was measured: +13 % time at M=250, +6 % at M=500; profiles/README.md.)
+    constexpr bool HOIST = NI <= 2; // (4 NI registers)
+    auto lane_consts = [&](int j, uint32_t &row_c, uint32_t &k_ofs, uint32_t &rk, uint32_t &kl) __attribute__((always_inline)) {
+        // granule G of the LDS image is written by lane `lane` of DMA instruction (wave, j)
+        const int G = (wave * NI + j) * 64 + lane;
+        // image [TM rows][KC k]; granule slot gs of a row holds k = 2*(gs ^ swz(row)), +1
+        const int row = G / (KC / 2), gs = G % (KC / 2);
+        const int swz = KC == 16 ? ((row >> 1) & 7) : (row & 15);
+        row_c = (uint32_t)min(row, item.rows - 1), k_ofs = (uint32_t)(2 * (gs ^ swz));
+        // fragment-major image [f][k][16 rows]: granule = rows (f*16 + 2p, +1) of one k
+        const int f = G / (KC * 8), p2 = G & 7;
+        rk = (uint32_t)min(f * 16 + 2 * p2, item.rows - 1), kl = (uint32_t)((G % (KC * 8)) >> 3);
+    };
+    uint32_t h_rowc[HOIST ? NI : 1], h_kofs[HOIST ? NI : 1], h_rk[HOIST ? NI : 1], h_kl[HOIST ? NI : 1];
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int j = 0; j < NI; j++)
+            lane_consts(j, h_rowc[j], h_kofs[j], h_rk[j], h_kl[j]);
+    }
+    const int cbase0 = wave * (CF * 16) + c; // this lane's column in the tile (first column fragment)
     auto lane_offsets = [&](const GSeg &S, int kb, bool part) __attribute__((always_inline)) {
-        const uint32_t akmax = (uint32_t)(S.K - 1 - kb) * astep; // relative to the chunk base
+        const int n = S.K - kb;                                 // valid k of this chunk (part: n < KC)
+        const uint32_t kcl = part ? (uint32_t)(n - 1) : 0xFFFFu; // largest k offset that may be fetched
 #pragma unroll
         for (int j = 0; j < NI; j++) {
-            // granule G of the LDS image is written by lane `lane` of DMA instruction (wave, j)
-            const int G = (wave * NI + j) * 64 + lane;
-            uint32_t ro, ko;
-            if (s_kmaj) { // fragment-major image [f][k][16 rows]: granule = rows (f*16 + 2p, +1) of one k
-                const int f = G / (KC * 8), kl = (G % (KC * 8)) >> 3, p2 = G & 7;
-                ro = (uint32_t)min(f * 16 + 2 * p2, S.mr - 1);
-                ko = (uint32_t)kl * astep;
-            } else { // image [TM rows][KC k]; granule slot gs of a row holds k = 2*(gs ^ swz(row)), +1
-                const int row = G / (KC / 2), gs = G % (KC / 2);
-                const int swz = KC == 16 ? ((row >> 1) & 7) : (row & 15);
-                ro = (uint32_t)min(row, S.mr - 1) * (uint32_t)S.a_sr;
-                ko = (uint32_t)(2 * (gs ^ swz));
-            }
-            va[j] = (ro + (part ? min(ko, akmax) : ko)) * 8u;
+            uint32_t row_c, k_ofs, rk, kl;
+            if constexpr (HOIST)
+                row_c = h_rowc[j], k_ofs = h_kofs[j], rk = h_rk[j], kl = h_kl[j];
+            else
+                lane_consts(j, row_c, k_ofs, rk, kl);
+            // (a segment's rows always cover its tile: S.mr == item.rows, which lane_consts clamps to)
+            va[j] = (s_kmaj ? __umul24(min(kl, kcl), astep) + rk : __umul24(row_c, (uint32_t)S.a_sr) + min(k_ofs, kcl)) << 3;
         }
-        const uint32_t bkmax = (uint32_t)(S.K - 1 - kb) * bstep;
+        uint32_t kt[KS]; // this lane's k of every k-step, times the k stride of B
+#pragma unroll
+        for (int s = 0; s < KS; s++) // full chunk: the k-step's 4 s rows are in the scalar base; partial: base = chunk start
+            kt[s] = __umul24(min((uint32_t)g + (part ? 4u * s : 0u), kcl), bstep);
+        // k-steps in which this lane's k is valid: 4 s + g < n
+        const uint32_t kbits = part ? ((1u << ((n - g + 3) >> 2)) - 1u) : ((1u << KS) - 1u);
         bmask = 0;
 #pragma unroll
         for (int q = 0; q < CF; q++) {
-            const int cc = wave * (CF * 16) + q * 16 + c - S.tc0;
-            const bool in = cc >= 0 && cc < S.nc;
-            const uint32_t co = (uint32_t)min(max(cc, 0), S.nc - 1) * (uint32_t)S.b_sc;
+            const int cc = cbase0 + q * 16 - S.tc0;
+            const bool in = (uint32_t)cc < (uint32_t)S.nc;
+            const uint32_t co = __umul24((uint32_t)min(max(cc, 0), S.nc - 1), (uint32_t)S.b_sc);
 #pragma unroll
-            for (int s = 0; s < KS; s++) {
-                // full chunk: the k-step's 4 s rows are in the scalar base; partial chunk: base = chunk start
-                vb[q][s] = (co + (part ? min((uint32_t)(4 * s + g) * bstep, bkmax) : (uint32_t)g * bstep)) * 8u;
-                bmask |= (uint32_t)(in && (!part || kb + 4 * s + g < S.K)) << (q * KS + s);
-            }
+            for (int s = 0; s < KS; s++)
+                vb[q][s] = (co + kt[s]) << 3;
+            bmask |= in ? kbits << (q * KS) : 0u;
         }
         tail = part;
         bmasked = part || !cols_full;
@@ -342,8 +370,12 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
 #pragma unroll
         for (int q = 0; q < CF; q++)
 #pragma unroll
-            for (int s = 0; s < KS; s++)
-                bcur[q][s] = ((bmask >> (q * KS + s)) & 1) ? (SB ? bnxt[q][s] * salpha : bnxt[q][s]) : 0.0;
+            for (int s = 0; s < KS; s++) { // all-ones / zero word from the lane's mask bit, then two ANDs
+                const int32_t m = (int32_t)(bmask << (31 - (q * KS + s))) >> 31;
+                const double v = SB ? bnxt[q][s] * salpha : bnxt[q][s];
+                const uint64_t u = (uint64_t)__double_as_longlong(v) & (uint64_t)(int64_t)m;
+                bcur[q][s] = __longlong_as_double((long long)u);
+            }
     };
     // the MFMA block: all TMF x CF fragments, branch-free
     // Pin the issue order inside the MFMA block: LDS reads run LEAD fragments ahead of the MFMAs that consume
@@ -529,24 +561,27 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
 // CF = 1 workgroup (one per CU) this halves the ds_reads per MFMA (an A fragment feeds two MFMAs), gives the SIMD
 // partners independent barriers, and wastes less on the many sectors shorter than 256 rows:
 // M=1000 26.2 -> 29.6, M=4000 52.3 -> 55.2 TFLOP/s on the bench plan, 62.3 on uniform 1024^3 pairs.
-template <int CF, int NW, int KC, bool SB>
-__global__ __launch_bounds__(NW * 64, 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
+// TMAX = tallest tile (in 16-row fragments) this instantiation serves.  The register count of a kernel is that of its
+// tallest body, so the short tiles (<= 16 kGGShortFrags = 48 rows: the sectors of small bond dimensions, where a segment
+// is one or two chunks long and the exposed load latency, not the MFMA pipe, sets the pace) get an instantiation of
+// their own with half the registers (<= 128: no spills up to three row fragments) and 3/8 of the LDS: four waves per
+// SIMD instead of two hide that latency.
+template <int CF, int NW, int KC, bool SB, int TMAX>
+__global__ __launch_bounds__(NW * 64, TMAX <= kGGShortFrags ? 4 : 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
                                                          const double *__restrict__ arena,
                                                          const double *__restrict__ psi, double *__restrict__ scratch,
                                                          double *__restrict__ slabs) {
-    __shared__ __attribute__((aligned(16))) double lds[2 * kGGTileM * KC];
+    __shared__ __attribute__((aligned(16))) double lds[2 * TMAX * 16 * KC];
     const GItem item = items[blockIdx.x];
 #define B2X_GG_CASE(T)                                                                                                 \
     case T:                                                                                                            \
-        if constexpr (T * 16 <= kGGTileM)                                                                              \
-            gg_body<T, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);                                   \
+        if constexpr (T <= TMAX)                                                                                       \
+            gg_body<T, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);               \
         break;
     switch ((item.rows + 15) >> 4) { // row fragments of the tile
         B2X_GG_CASE(1) B2X_GG_CASE(2) B2X_GG_CASE(3) B2X_GG_CASE(4) B2X_GG_CASE(5) B2X_GG_CASE(6) B2X_GG_CASE(7)
-        B2X_GG_CASE(8) B2X_GG_CASE(9) B2X_GG_CASE(10) B2X_GG_CASE(11) B2X_GG_CASE(12) B2X_GG_CASE(13) B2X_GG_CASE(14)
-        B2X_GG_CASE(15)
     default:
-        gg_body<kGGTileM / 16, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);
+        gg_body<TMAX, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);
     }
 #undef B2X_GG_CASE
 }
@@ -835,28 +870,34 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
     return hipErrorInvalidValue;
 }
 
-// items of all tile-height variants in one grid: v_begin[0] .. v_begin[kGGVariants]
+// items of one stage: [v_begin[0], v_begin[1]) tall tiles (> 16 kGGShortFrags rows), [v_begin[1], v_begin[kGGVariants]) short ones;
+// each class is one launch of the instantiation that serves it
 hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_begin, const double *arena,
                      const double *psi, double *scratch, double *slabs, bool seg_scaled, int tile_n, hipStream_t st) {
-    const uint32_t n = v_begin[kGGVariants] - v_begin[0];
-    if (n == 0)
-        return hipSuccess;
     // chunk depth 16: a 32-deep chunk halves the barriers (+2 % on uniform 1024^3 pairs) but pads every K to 32 and
     // spills at 256 VGPRs (-2 % on the M=4000 plan)
-#define B2X_GG_LAUNCH(NWV, SBV)                                                                                        \
-    hipLaunchKernelGGL((gg_kernel<kGGCF, NWV, 16, SBV>), dim3(n), dim3(NWV * 64), 0, st, segs, items + v_begin[0], arena, \
-                       psi, scratch, slabs)
+#define B2X_GG_LAUNCH(NWV, SBV, TMAXV, B, E)                                                                           \
+    if ((E) > (B))                                                                                                     \
+    hipLaunchKernelGGL((gg_kernel<kGGCF, NWV, 16, SBV, TMAXV>), dim3((E) - (B)), dim3(NWV * 64), 0, st, segs, items + (B), \
+                       arena, psi, scratch, slabs)
     const int nw = tile_n / (16 * kGGCF); // waves per workgroup: 4 (128-column tiles) or 2 (narrow sectors)
+    const uint32_t b0 = v_begin[0], b1 = v_begin[1], b2 = v_begin[kGGVariants];
     if (nw >= 4) {
-        if (seg_scaled)
-            B2X_GG_LAUNCH(4, true);
-        else
-            B2X_GG_LAUNCH(4, false);
+        if (seg_scaled) {
+            B2X_GG_LAUNCH(4, true, 8, b0, b1);
+            B2X_GG_LAUNCH(4, true, kGGShortFrags, b1, b2);
+        } else {
+            B2X_GG_LAUNCH(4, false, 8, b0, b1);
+            B2X_GG_LAUNCH(4, false, kGGShortFrags, b1, b2);
+        }
     } else { // (the plan compiler picks 128- or 64-column tiles)
-        if (seg_scaled)
-            B2X_GG_LAUNCH(2, true);
-        else
-            B2X_GG_LAUNCH(2, false);
+        if (seg_scaled) {
+            B2X_GG_LAUNCH(2, true, 8, b0, b1);
+            B2X_GG_LAUNCH(2, true, kGGShortFrags, b1, b2);
+        } else {
+            B2X_GG_LAUNCH(2, false, 8, b0, b1);
+            B2X_GG_LAUNCH(2, false, kGGShortFrags, b1, b2);
+        }
     }
 #undef B2X_GG_LAUNCH
     return hipGetLastError();

@@ -505,6 +505,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     }
             }
             const uint32_t s1_begin = (uint32_t)out.gitems.size();
+            std::vector<uint32_t> tile_of_item; // stage-1 items in creation order -> running number of their tile
+            uint32_t tile_seq = 0, tile_sector = 0;
             ss.tile_begin = (uint32_t)out.gtiles.size();
             // stage 1: per component, per psi' tile, the segments of this step's pairs
             uint64_t slab = 0;
@@ -673,6 +675,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                                 it.out_off = slab, it.out_ld = dt.cols, it.rows = dt.rows, it.cols = dt.cols;
                                 it.alpha = 1.0, it.out_kind = 0;
                                 out.gitems.push_back(it);
+                                tile_of_item.push_back(tile_seq);
                                 slab += (uint64_t)dt.rows * dt.cols;
                                 begin = it.seg_end;
                                 made++;
@@ -680,7 +683,15 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         }
                         dt.n_items = made;
                         out.gtiles.push_back(dt);
+                        // sibling order: 4 x 4 blocks of tiles (a tile shares its A operands with the tiles of its row and
+                        // its B operands with those of its column: a square block shares both)
+                        const uint32_t blk = (uint32_t)((a / 4) * ceil_div(nct, 4) + b / 4);
+                        const uint32_t key = (tile_sector << 20) | (blk << 4) | (uint32_t)((a % 4) * 4 + b % 4);
+                        for (int m2 = 0; m2 < made; m2++)
+                            tile_of_item[tile_of_item.size() - 1 - m2] = key;
+                        tile_seq++;
                     }
+                tile_sector++;
                 i = j;
             }
             const uint32_t s1_end = (uint32_t)out.gitems.size();
@@ -696,14 +707,85 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             };
             auto order = [&](const GItem &x, const GItem &y) { return icost(x) > icost(y); };
             std::stable_sort(out.gitems.begin() + s0_begin, out.gitems.begin() + s1_begin, order);
-            std::stable_sort(out.gitems.begin() + s1_begin, out.gitems.begin() + s1_end, order);
-            auto fill = [&](uint32_t b, uint32_t e, uint32_t *v) { // variants share one launch: [v[0], v[last])
-                for (int k = 0; k < kGGVariants; k++)
-                    v[k] = b;
-                v[kGGVariants] = e;
+            // tall tiles first, short ones (<= kGGShortFrags row fragments) behind them: each class is one launch of the
+            // kernel instantiation that serves it (launch_gg); the cost order holds inside a class
+            // A second launch costs a second tail: the short class gets its own launch only where it carries most of the
+            // stage (>= 60 % of the MFMA issue slots: M=250 -24 % time; a minority of short tiles rides along in the tall
+            // launch, as before: split regardless, M=1000 lost 11 % and the Hubbard M=3000 plan 9 %)
+            auto short_share = [&](uint32_t b, uint32_t e) {
+                double tot = 0, sh = 0;
+                for (uint32_t ii = b; ii < e; ii++) {
+                    const double c = (double)icost(out.gitems[ii]);
+                    tot += c;
+                    if (out.gitems[ii].rows <= kGGShortFrags * kGGRowUnit)
+                        sh += c;
+                }
+                return tot > 0 ? sh / tot : 0.0;
             };
-            fill(s0_begin, s1_begin, ss.s0_v);
-            fill(s1_begin, s1_end, ss.s1_v);
+            const bool split0 = short_share(s0_begin, s1_begin) >= 0.6, split1 = short_share(s1_begin, s1_end) >= 0.6;
+            auto tall = [](const GItem &x) { return x.rows > kGGShortFrags * kGGRowUnit; };
+            const uint32_t s0_mid = !split0 ? s1_begin
+                                            : (uint32_t)(std::stable_partition(out.gitems.begin() + s0_begin,
+                                                                               out.gitems.begin() + s1_begin, tall) -
+                                                         out.gitems.begin());
+            uint32_t s1_mid = s1_begin;
+            // Stage 1: longest first ACROSS sibling groups, siblings together inside a group.  Items of equal cost that
+            // take the same K range (item index j) of neighbouring tiles of one sector walk the same operands: the tiles of
+            // a row share their A blocks, the tiles of a column their B blocks.  Workgroup ids i, i + 8, i + 16, ... run on
+            // one XCD (one L2), so after the cost order every window of 8 g items is transposed: XCD x receives g
+            // consecutive siblings instead of every eighth one.  The longest-first order is kept to within one window.
+            {
+                struct Key {
+                    uint64_t cost;
+                    uint32_t j, seq, idx;
+                };
+                std::vector<Key> keys;
+                keys.reserve(s1_end - s1_begin);
+                uint32_t seq = 0, j = 0;
+                for (uint32_t ii = s1_begin; ii < s1_end; ii++) { // (creation order: tile by tile, items of a tile in a row)
+                    const GItem &it = out.gitems[ii];
+                    const bool same_tile = ii > s1_begin && tile_of_item[ii - s1_begin] == tile_of_item[ii - 1 - s1_begin];
+                    j = same_tile ? j + 1 : 0;
+                    seq = tile_of_item[ii - s1_begin];
+                    keys.push_back(Key{icost(it), j, seq, ii});
+                }
+                std::stable_sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) {
+                    if (x.cost != y.cost)
+                        return x.cost > y.cost;
+                    if (x.j != y.j)
+                        return x.j < y.j;
+                    return x.seq < y.seq;
+                });
+                // g = 16 siblings per XCD and window (measured on the M=4000 plan: FETCH_SIZE -12 %, time -1 %; g = 4 ... 64
+                // within 2 % of each other; B2X_XCD_G overrides, 0 = plain cost order)
+                static const int xg = getenv("B2X_XCD_G") ? atoi(getenv("B2X_XCD_G")) : 16;
+                std::vector<GItem> sorted;
+                sorted.reserve(keys.size());
+                for (const Key &k : keys)
+                    sorted.push_back(out.gitems[k.idx]);
+                const size_t n_tall = !split1 ? sorted.size() : (size_t)(std::stable_partition(sorted.begin(), sorted.end(), tall) - sorted.begin());
+                s1_mid = s1_begin + (uint32_t)n_tall;
+                if (xg > 1) {
+                    const size_t W = (size_t)8 * xg;
+                    std::vector<GItem> tmp(W);
+                    const size_t lim[3] = {0, n_tall, sorted.size()};
+                    for (int cl = 0; cl < 2; cl++) // (a window never straddles the two launches)
+                        for (size_t b = lim[cl]; b + W <= lim[cl + 1]; b += W) {
+                            for (size_t x = 0; x < 8; x++)
+                                for (size_t k = 0; k < (size_t)xg; k++)
+                                    tmp[8 * k + x] = sorted[b + x * xg + k];
+                            std::copy(tmp.begin(), tmp.end(), sorted.begin() + b);
+                        }
+                }
+                std::copy(sorted.begin(), sorted.end(), out.gitems.begin() + s1_begin);
+            }
+            auto fill = [&](uint32_t b, uint32_t mid, uint32_t e, uint32_t *v) { // [v[0], v[1]) tall, [v[1], v[last]) short tiles
+                v[0] = b, v[1] = mid;
+                for (int k = 2; k <= kGGVariants; k++)
+                    v[k] = e;
+            };
+            fill(s0_begin, s0_mid, s1_begin, ss.s0_v);
+            fill(s1_begin, s1_mid, s1_end, ss.s1_v);
             for (uint32_t ii = s0_begin; ii < s1_end; ii++) {
                 const GItem &it = out.gitems[ii];
                 uint64_t tm = (uint64_t)kGGRowUnit * (uint64_t)(variant(it) + 1);
@@ -894,7 +976,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         st.macs_alg_dominant = (uint64_t)(gg_macs_total + 0.5); // reference count of the pairs on this path
         st.n_launches = 0;
         for (const SuperStep &ss : out.steps)
-            st.n_launches += (ss.s0_v[kGGVariants] > ss.s0_v[0]) + (ss.s1_v[kGGVariants] > ss.s1_v[0]);
+            st.n_launches += (ss.s0_v[1] > ss.s0_v[0]) + (ss.s0_v[kGGVariants] > ss.s0_v[1]) + (ss.s1_v[1] > ss.s1_v[0]) +
+                             (ss.s1_v[kGGVariants] > ss.s1_v[1]);
     }
     stage_residual_reads(out, std::max(arena_cap, arena_len), psi_len);
     st.device_bytes = (out.scratch_elems + out.gslab_elems) * 8 + out.gsegs.size() * sizeof(GSeg) +
@@ -1211,9 +1294,21 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
         return k * (uint64_t)(variant(x) + 1);
     };
     std::stable_sort(out.gitems.begin(), out.gitems.end(), [&](const GItem &x, const GItem &y) { return icost(x) > icost(y); });
+    double c_tot = 0, c_short = 0; // (same rule as compile_plan: a launch of its own where the short tiles carry the list)
+    for (const GItem &x : out.gitems) {
+        const double c = (double)icost(x);
+        c_tot += c;
+        if (x.rows <= kGGShortFrags * kGGRowUnit)
+            c_short += c;
+    }
+    const uint32_t n_tall = !(c_tot > 0 && c_short / c_tot >= 0.6)
+                                ? (uint32_t)out.gitems.size()
+                                : (uint32_t)(std::stable_partition(out.gitems.begin(), out.gitems.end(), [](const GItem &x) {
+                                                 return x.rows > kGGShortFrags * kGGRowUnit;
+                                             }) - out.gitems.begin());
     for (int k = 0; k <= kGGVariants; k++)
-        ss.s0_v[k] = 0, ss.s1_v[k] = 0;
-    ss.s1_v[kGGVariants] = (uint32_t)out.gitems.size();
+        ss.s0_v[k] = 0, ss.s1_v[k] = (uint32_t)out.gitems.size();
+    ss.s1_v[0] = 0, ss.s1_v[1] = n_tall; // [0, n_tall) tall tiles, [n_tall, end) short ones (launch_gg)
     ss.tile_begin = 0, ss.tile_end = (uint32_t)out.gtiles.size();
     ss.sum_begin = 0, ss.sum_end = (uint32_t)out.sum_work.size();
     for (const GItem &it : out.gitems) {
@@ -1226,7 +1321,8 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     stage_residual_reads(out, std::max(arena_cap, arena_len), in_len);
     st.n_tiles = out.gtiles.size(), st.n_items = out.gitems.size(), st.n_parts = out.gsegs.size();
     st.macs_executed = gg_macs;
-    st.dominant_class = kNumClasses, st.macs_dominant = gg_macs, st.macs_alg_dominant = st.macs, st.n_launches = 1;
+    st.dominant_class = kNumClasses, st.macs_dominant = gg_macs, st.macs_alg_dominant = st.macs;
+    st.n_launches = (n_tall > 0) + (out.gitems.size() > n_tall);
     st.device_bytes = out.gslab_elems * 8 + out.gsegs.size() * sizeof(GSeg) + out.gitems.size() * sizeof(GItem) +
                       out.gtiles.size() * sizeof(DTile) + out.scratch_elems * 8 + out.sum_work.size() * sizeof(OWork) +
                       out.sum_entries.size() * sizeof(OEntry);

@@ -123,6 +123,7 @@ struct SuperStep {
 static const int kGGTileM = 128, kGGTileN = 128;
 static const int kGGCF = 2;
 static const int kGGRowUnit = 16; // tile heights are multiples of one MFMA row fragment
+static const int kGGShortFrags = 3; // tiles of up to this many row fragments run on the low-register kernel instantiation
 
 // kernel classes of the fused path.  nw = tile width / 16, tmf = tile height / 16, k1f = k1 chunk / 16.
 // All fused classes run hpsi_wave — one WAVE per work item, operands straight from L2 into MFMA fragments, no LDS,

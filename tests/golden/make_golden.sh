@@ -70,3 +70,6 @@ $R $D/N2.STO3G.FCIDUMP su2 200 2 ./chain_n2su2/n2c chain=1 nodelay=1 nocache=1 n
 $R $D/N2.STO3G.FCIDUMP su2 60 2 ./diskc_n2su2 tensor_file=4 fp_prec=1e-8 fp_chunk=64 iprint=0
 $R $D/H10.STO6G.R1.8.FCIDUMP sz 30 2 ./diskc_h10sz tensor_file=5 fp_prec=1e-5 fp_chunk=1024 iprint=0
 $R $D/N2.STO3G.FCIDUMP su2 60 2 ./x stop_after=1:4 iprint=0 scratch=/tmp/b2x_listing && ls /tmp/b2x_listing > scratch_listing.txt
+# the Cr2 site-20 plan WITHOUT occupation-guided initial bond dimensions (what SURVEY.md counted: 400-570 k pairs) ->
+# cr2_su2_m250_noocc_sw1_site20.struct.npz
+$R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2noocc struct=1:20 stop_after=1:20 noise=1e-5,1e-5 iprint=0

@@ -7,7 +7,7 @@ cd $R
 for rep in 1 2; do
 for w in $2; do
   for l in $1; do
-    B2X_LIB=$R/block2-preview_amd/$l timeout -k 10 300 python bench.py --workload $w --steps 6 --warmup 2 --no-cpu > $out/${l}_${w}_$rep.json 2> $out/${l}_${w}_$rep.err || echo "bench $l $w failed"
+    B2X_LIB=$R/block2-preview_amd/$l timeout -k 10 300 python bench.py --workload $w --steps 6 --warmup 2 --no-cpu --site-step 0 > $out/${l}_${w}_$rep.json 2> $out/${l}_${w}_$rep.err || echo "bench $l $w failed"
     python - $out/${l}_${w}_$rep.json $l <<'PY'
 import json,sys
 j=json.load(open(sys.argv[1])); r=j["roofline"]
