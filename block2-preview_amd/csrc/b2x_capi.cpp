@@ -70,6 +70,9 @@ struct b2x_plan {
     OEntry *d_sum_entries = nullptr;
     std::vector<SuperStep> steps;
     std::vector<StageCopy> stage_in; // input-vector operands copied into the scratch at the start of every execute
+    // the short-tile class of a stage runs beside the tall one on a stream of its own (fork / join with events)
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     double *d_psi = nullptr, *d_sigma = nullptr; // staging for host-pointer execute
     size_t psi_len = 0, sigma_len = 0;
     int dominant_cls = 0;
@@ -108,6 +111,12 @@ static void plan_free(b2x_plan *p) {
         (void)hipFree(p->d_psi);
     if (p->d_sigma)
         (void)hipFree(p->d_sigma);
+    if (p->aux_stream)
+        (void)hipStreamDestroy(p->aux_stream);
+    if (p->ev_fork)
+        (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join)
+        (void)hipEventDestroy(p->ev_join);
     delete p;
 }
 
@@ -385,6 +394,27 @@ int b2x_gemm_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_gemms,
     return plan_upload(out, arena, cp, 0, nullptr, in_len, out_len, nullptr);
 }
 
+// one stage of a super-step: both tile classes, the short one on the plan's own stream beside the tall one
+static int launch_stage(b2x_plan *p, const uint32_t *v, const double *psi, hipStream_t st) {
+    const bool both = v[1] > v[0] && v[kGGVariants] > v[1];
+    if (!both) {
+        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st, 0));
+        return B2X_OK;
+    }
+    if (!p->aux_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+    }
+    HIPCHK(hipEventRecord(p->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(p->aux_stream, p->ev_fork, 0));
+    HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, p->aux_stream, 2));
+    HIPCHK(hipEventRecord(p->ev_join, p->aux_stream));
+    HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st, 1));
+    HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
+    return B2X_OK;
+}
+
 static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale, hipStream_t st) {
     if (p->fallback) {
         HIPCHK(launch_generic(p->d_pairs, p->n_pairs, p->arena->dev, psi, sigma, scale, st));
@@ -396,11 +426,14 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
     for (const StageCopy &sc : p->stage_in) // (degenerate operands at the very end of the input vector; normally none)
         HIPCHK(hipMemcpyAsync(p->d_scratch + sc.dst_off, psi + sc.src_off, sc.len * sizeof(double), hipMemcpyDeviceToDevice, st));
     for (const SuperStep &ss : p->steps) {
-        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st));
+        int rc = launch_stage(p, ss.s0_v, psi, st);
+        if (rc != B2X_OK)
+            return rc;
         if (ss.sum_end > ss.sum_begin)
             HIPCHK(launch_outer(p->d_sum_work + ss.sum_begin, ss.sum_end - ss.sum_begin, p->d_sum_entries, p->arena->dev,
                                 p->d_scratch, p->d_scratch, 16, st));
-        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st));
+        if ((rc = launch_stage(p, ss.s1_v, psi, st)) != B2X_OK)
+            return rc;
         HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st));
     }
     return B2X_OK;
@@ -457,13 +490,19 @@ int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, 
             // bracketed together; fused classes + reduces make up the rest of the total
             HIPCHK(hipEventRecord(e0, st));
             for (const SuperStep &ss : p->steps) {
-                HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s0_v, p->arena->dev, psi_dev, p->d_scratch,
-                                 p->d_gslabs, p->seg_scaled, p->gg_tile_n, st));
+                {
+                    int rc0 = launch_stage(p, ss.s0_v, psi_dev, st);
+                    if (rc0 != B2X_OK)
+                        return rc0;
+                }
                 if (ss.sum_end > ss.sum_begin)
                     HIPCHK(launch_outer(p->d_sum_work + ss.sum_begin, ss.sum_end - ss.sum_begin, p->d_sum_entries,
                                         p->arena->dev, p->d_scratch, p->d_scratch, 16, st));
-                HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, ss.s1_v, p->arena->dev, psi_dev, p->d_scratch,
-                                 p->d_gslabs, p->seg_scaled, p->gg_tile_n, st));
+                {
+                    int rc1 = launch_stage(p, ss.s1_v, psi_dev, st);
+                    if (rc1 != B2X_OK)
+                        return rc1;
+                }
             }
             HIPCHK(hipEventRecord(e1, st));
             HIPCHK(hipEventSynchronize(e1));

@@ -709,9 +709,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             std::stable_sort(out.gitems.begin() + s0_begin, out.gitems.begin() + s1_begin, order);
             // tall tiles first, short ones (<= kGGShortFrags row fragments) behind them: each class is one launch of the
             // kernel instantiation that serves it (launch_gg); the cost order holds inside a class
-            // A second launch costs a second tail: the short class gets its own launch only where it carries most of the
-            // stage (>= 60 % of the MFMA issue slots: M=250 -24 % time; a minority of short tiles rides along in the tall
-            // launch, as before: split regardless, M=1000 lost 11 % and the Hubbard M=3000 plan 9 %)
+            // The short class gets its own launch (on the plan's auxiliary stream, beside the tall one: launch_stage in
+            // b2x_capi.cpp) where it carries at least 30 % of the stage's MFMA issue slots: M=250 -20 % time, M=500 -5 %,
+            // the uniform-bond-dimension Cr2 plan at M=1000 -11 %; below that share the few short tiles ride along in the
+            // tall launch (split regardless: M=1000 +1.5 %).  B2X_SPLIT_THR overrides (2 = never split).
             auto short_share = [&](uint32_t b, uint32_t e) {
                 double tot = 0, sh = 0;
                 for (uint32_t ii = b; ii < e; ii++) {
@@ -722,7 +723,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 }
                 return tot > 0 ? sh / tot : 0.0;
             };
-            const bool split0 = short_share(s0_begin, s1_begin) >= 0.6, split1 = short_share(s1_begin, s1_end) >= 0.6;
+            static const double thr = getenv("B2X_SPLIT_THR") ? atof(getenv("B2X_SPLIT_THR")) : 0.3;
+            const bool split0 = short_share(s0_begin, s1_begin) >= thr, split1 = short_share(s1_begin, s1_end) >= thr;
             auto tall = [](const GItem &x) { return x.rows > kGGShortFrags * kGGRowUnit; };
             const uint32_t s0_mid = !split0 ? s1_begin
                                             : (uint32_t)(std::stable_partition(out.gitems.begin() + s0_begin,
@@ -1294,14 +1296,14 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
         return k * (uint64_t)(variant(x) + 1);
     };
     std::stable_sort(out.gitems.begin(), out.gitems.end(), [&](const GItem &x, const GItem &y) { return icost(x) > icost(y); });
-    double c_tot = 0, c_short = 0; // (same rule as compile_plan: a launch of its own where the short tiles carry the list)
+    double c_tot = 0, c_short = 0; // (same rule as compile_plan: a launch of its own where the short tiles carry enough of the list)
     for (const GItem &x : out.gitems) {
         const double c = (double)icost(x);
         c_tot += c;
         if (x.rows <= kGGShortFrags * kGGRowUnit)
             c_short += c;
     }
-    const uint32_t n_tall = !(c_tot > 0 && c_short / c_tot >= 0.6)
+    const uint32_t n_tall = !(c_tot > 0 && c_short / c_tot >= 0.3)
                                 ? (uint32_t)out.gitems.size()
                                 : (uint32_t)(std::stable_partition(out.gitems.begin(), out.gitems.end(), [](const GItem &x) {
                                                  return x.rows > kGGShortFrags * kGGRowUnit;
