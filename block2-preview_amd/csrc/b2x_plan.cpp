@@ -262,7 +262,12 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         shapes[ci].macs = sector_macs, shapes[ci].max_k = max_k;
         any_must = any_must || shapes[ci].must;
     }
-    any_must = any_must || (double)st.macs > 1e9;
+    // Since the grouped-GEMM kernel has a low-register instantiation for short tiles (four waves per SIMD) and its own
+    // cheap per-segment arithmetic, it beats the fused wave kernel on every plan measured, small ones included (golden
+    // N2 / H10 / Hubbard plans 1.0-2.8x, H10 at M=500 2.6x: the fused path pays three launches, recomputes stage 0 per
+    // row tile and reads every partial slab back; profiles/r02_route_probe.txt): auto routing sends every plan there.
+    // The fused wave kernel stays available (b2x_plan_options.two_stage = -1) and tested.
+    any_must = true;
     for (const Component &c : comps) {
         // auto routing: the fused kernel recomputes stage 0 per row tile and keeps W in registers, which
         // pays for sectors that fit one tile; tall / wide / deep ones go to the grouped-GEMM path
@@ -272,7 +277,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         // applies.  Measured on the Cr2 plan: M=250 1.74 ms fused -> 1.30 ms; M=500 8.0 -> 6.9 ms when the small sectors
         // followed the large ones; mixed plans (some sectors fused) were never faster than all-grouped.  Small plans
         // (the N2 / H10 test sizes) stay on the fused wave kernel.
-        const bool large = any_must;
+        const bool large = any_must && !(opt && opt->tile_n > 0); // (a forced fused-tile class, as the tests ask for, keeps the wave kernel)
         if (two_stage > 0 || (two_stage == 0 && large)) {
             big.push_back(&c);
             continue;
