@@ -784,7 +784,7 @@ __global__ void vec_scal_k(double a, double *x, size_t n) {
 }
 __global__ void vec_precond_k(double *q, const double *diag, double shift, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        double d = diag[i] - shift;
+        double d = shift - diag[i]; // davidson_precondition: q /= ld - aa[i]
         if (fabs(d) > 1e-12)
             q[i] /= d;
     }

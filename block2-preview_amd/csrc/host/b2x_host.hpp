@@ -614,18 +614,66 @@ inline void small_eigs(std::vector<double> &a, std::vector<double> &w, int m) {
     a.swap(out);
 }
 
+// DavidsonTypes (src/core/matrix_functions.hpp:273-293): the same names and bit values (they are interface).
+enum struct DavidsonTypes : uint16_t {
+    Normal = 0,
+    GreaterThan = 1,
+    LessThan = 2,
+    CloseTo = 4,
+    Harmonic = 16,
+    HarmonicGreaterThan = 16 | 1,
+    HarmonicLessThan = 16 | 2,
+    HarmonicCloseTo = 16 | 4,
+    DavidsonPrecond = 32,
+    NoPrecond = 64,
+    NonHermitian = 128,
+    Exact = 256,
+    LeftEigen = 512,
+    ElementProj = 1024
+};
+inline bool operator&(DavidsonTypes a, DavidsonTypes b) { return ((uint16_t)a & (uint16_t)b) != 0; }
+inline DavidsonTypes operator|(DavidsonTypes a, DavidsonTypes b) { return DavidsonTypes((uint16_t)a | (uint16_t)b); }
+
+// The PComm argument of the reference's davidson: rank / root and a broadcast of DEVICE vectors (b2x_broadcast, RCCL).
+struct DeviceComm {
+    b2x_comm *comm = nullptr;
+    int rank = 0, size = 1, root = 0;
+    void broadcast(double *dev, size_t n) const { check(b2x_broadcast(comm, dev, n, root, nullptr)); }
+};
+
 struct IterativeMatrixFunctions {
-    // Davidson for the k lowest eigenpairs, every psi-sized vector resident on the device.
+    // Davidson for k eigenpairs, every psi-sized vector resident on the device.
     //   op(b_dev, sigma_dev): sigma += H b   (sigma arrives zeroed, as in the reference :972-973)
-    //   aa_dev: diagonal of H (Olsen preconditioner), vs_dev: k initial guesses, overwritten with eigenvectors.
-    // Same control flow as the reference (:864-1173): orthonormalise guesses, expand by one preconditioned
-    // residual per iteration, full Rayleigh-Ritz rotation of (b, sigma) each iteration, converge on
-    // |r|^2 < conv_thrd, collapse to deflation_min_size vectors at deflation_max_size.
+    //   aa_dev: diagonal of H (preconditioner), vs_dev: k initial guesses, overwritten with eigenvectors.
+    // Same control flow as the reference (:864-1173): orthonormalise guesses (and project out ors), expand by one
+    // preconditioned residual per iteration, full Rayleigh-Ritz rotation of (b, sigma) each iteration, roots ordered by
+    // davidson_type / shift, converge on |r|^2 < conv_thrd + (ld rel_conv_thrd)^2, collapse to deflation_min_size
+    // vectors at deflation_max_size.  ors: states projected out ((1 - |v><v|), or H + w |v><v| when proj_weights is
+    // given, :888-893).  Sum-MPO (pcomm != nullptr): op() ends in the all-reduce of sigma, so every rank holds the same
+    // (b, sigma) and runs the SAME subspace step (bitwise: RCCL's all-reduce returns identical sums on every rank, the
+    // vec_* kernels reduce in a fixed order) instead of the reference's root-only step; the reference's broadcast of the
+    // new basis vectors (:968-970) is kept, the scalar broadcasts (:1094-1097) are not needed.
+    // Not built: Harmonic / NonHermitian / Exact / LeftEigen variants (other solvers of the reference).
     static std::vector<double> davidson(const std::function<void(const double *, double *)> &op, const double *aa_dev,
-                                        std::vector<double *> &vs_dev, size_t n, int &ndav, double conv_thrd = 5E-6,
-                                        int max_iter = 5000, int soft_max_iter = -1, int deflation_min_size = 2,
-                                        int deflation_max_size = 50, bool iprint = false) {
+                                        std::vector<double *> &vs_dev, size_t n, double shift,
+                                        DavidsonTypes davidson_type, int &ndav, bool iprint = false,
+                                        const DeviceComm *pcomm = nullptr, double conv_thrd = 5E-6,
+                                        double rel_conv_thrd = 0.0, int max_iter = 5000, int soft_max_iter = -1,
+                                        int deflation_min_size = 2, int deflation_max_size = 50,
+                                        const std::vector<double *> &ors = std::vector<double *>(),
+                                        const std::vector<double> &proj_weights = std::vector<double>()) {
+        if ((davidson_type & DavidsonTypes::Harmonic) || (davidson_type & DavidsonTypes::NonHermitian) ||
+            (davidson_type & DavidsonTypes::Exact) || (davidson_type & DavidsonTypes::LeftEigen))
+            throw std::runtime_error("davidson: Harmonic / NonHermitian / Exact / LeftEigen types are not built");
         const int k = (int)vs_dev.size();
+        int nor = (int)ors.size(), nwg = 0;
+        if (davidson_type & DavidsonTypes::ElementProj)
+            ;
+        else if (proj_weights.size() != 0) {
+            if (proj_weights.size() != ors.size())
+                throw std::runtime_error("davidson: proj_weights and ors differ in length");
+            nwg = (int)ors.size(), nor = 0;
+        }
         if (deflation_min_size < k)
             deflation_min_size = k;
         if (deflation_max_size < k + k / 2)
@@ -653,6 +701,18 @@ struct IterativeMatrixFunctions {
             check(b2x_vec_dot(x, y, n, &r, nullptr));
             return r;
         };
+        std::vector<double> or_normsqs(nor);
+        for (int i = 0; i < nor; i++) { // :912-918 (the ors are orthogonalised in place, as the reference does)
+            for (int j = 0; j < i; j++)
+                if (std::fabs(or_normsqs[j]) > 1E-14)
+                    check(b2x_vec_axpy(-dot(ors[j], ors[i]) / or_normsqs[j], ors[j], ors[i], n, nullptr));
+            or_normsqs[i] = dot(ors[i], ors[i]);
+        }
+        auto project_ors = [&](double *x) {
+            for (int j = 0; j < nor; j++)
+                if (std::fabs(or_normsqs[j]) > 1E-14)
+                    check(b2x_vec_axpy(-dot(ors[j], x) / or_normsqs[j], ors[j], x, n, nullptr));
+        };
         for (int i = 0; i < k; i++)
             check(b2x_vec_copy(vs_dev[i], bs[i], n, nullptr));
         int m = k;
@@ -668,14 +728,29 @@ struct IterativeMatrixFunctions {
                 throw std::runtime_error("Cannot generate initial guess 0 for Davidson (zero norm)!");
             check(b2x_vec_scal(1.0 / nrm, bs[i], n, nullptr));
         }
+        for (int i = 0; i < m && nor != 0; i++) {
+            project_ors(bs[i]);
+            double nrm = std::sqrt(dot(bs[i], bs[i]));
+            if (nrm * nrm < 1E-14)
+                throw std::runtime_error("Cannot generate initial guess " + std::to_string(i) +
+                                         " for Davidson unitary to all given states!");
+            check(b2x_vec_scal(1.0 / nrm, bs[i], n, nullptr));
+        }
         std::vector<double> eigvals(k), ld;
+        std::vector<int> idx(M);
         int ck = 0, msig = 0, xiter = 0;
         double qq = 0;
+        auto thrd = [&](double e) { return conv_thrd + e * e * rel_conv_thrd * rel_conv_thrd; };
         while (xiter < max_iter && (soft_max_iter == -1 || xiter < soft_max_iter)) {
             xiter++;
+            if (pcomm != nullptr && xiter != 1)
+                for (int i = msig; i < m; i++)
+                    pcomm->broadcast(bs[i], n);
             for (int i = msig; i < m; i++, msig++) {
                 check(b2x_vec_zero(sg[i], n, nullptr));
                 op(bs[i], sg[i]);
+                for (int j = 0; j < nwg; j++)
+                    check(b2x_vec_axpy(dot(ors[j], bs[i]) * proj_weights[j], ors[j], sg[i], n, nullptr));
             }
             // Rayleigh-Ritz in the current basis
             std::vector<double> alpha((size_t)m * m, 0.0), row(m);
@@ -696,37 +771,69 @@ struct IterativeMatrixFunctions {
                 for (int j = 0; j < m; j++)
                     std::swap(sg[j], ts[j]), std::swap(bs[j], tb[j]);
             }
+            for (int i = 0; i < m; i++)
+                idx[i] = i;
+            if (davidson_type & DavidsonTypes::CloseTo) // the root order of :1024-1049
+                std::sort(idx.begin(), idx.begin() + m,
+                          [&](int i, int j) { return std::fabs(ld[i] - shift) < std::fabs(ld[j] - shift); });
+            else if (davidson_type & DavidsonTypes::LessThan)
+                std::sort(idx.begin(), idx.begin() + m, [&](int i, int j) {
+                    if ((shift >= ld[i]) != (shift >= ld[j]))
+                        return shift >= ld[i];
+                    return shift >= ld[i] ? shift - ld[i] < shift - ld[j] : ld[i] - shift > ld[j] - shift;
+                });
+            else if (davidson_type & DavidsonTypes::GreaterThan)
+                std::sort(idx.begin(), idx.begin() + m, [&](int i, int j) {
+                    if ((shift > ld[i]) != (shift > ld[j]))
+                        return shift > ld[j];
+                    return shift > ld[i] ? shift - ld[i] > shift - ld[j] : ld[i] - shift < ld[j] - shift;
+                });
             for (int i = 0; i < ck; i++) { // re-check the roots already counted as converged
-                check(b2x_vec_copy(sg[i], q, n, nullptr));
-                check(b2x_vec_axpy(-ld[i], bs[i], q, n, nullptr));
-                if (std::fabs(dot(q, q)) >= conv_thrd) {
+                const int ii = idx[i];
+                check(b2x_vec_copy(sg[ii], q, n, nullptr));
+                check(b2x_vec_axpy(-ld[ii], bs[ii], q, n, nullptr));
+                if (std::fabs(dot(q, q)) >= thrd(ld[ii])) {
                     ck = i;
                     break;
                 }
             }
-            check(b2x_vec_copy(sg[ck], q, n, nullptr));
-            check(b2x_vec_axpy(-ld[ck], bs[ck], q, n, nullptr));
+            const int ick = idx[ck];
+            check(b2x_vec_copy(sg[ick], q, n, nullptr));
+            check(b2x_vec_axpy(-ld[ick], bs[ick], q, n, nullptr));
+            project_ors(q);
             qq = dot(q, q);
             if (iprint)
-                printf("%6d%6d%6d%15.8f%13.2e\n", xiter, m, ck, ld[ck], std::fabs(qq));
-            // olsen_precondition(q, bs[ck], ld[ck], aa)
-            check(b2x_vec_olsen_prepare(q, t, bs[ck], aa_dev, ld[ck], n, nullptr));
-            {
-                double cq = dot(bs[ck], q), ct = dot(bs[ck], t);
+                printf("%6d%6d%6d%15.8f%13.2e\n", xiter, m, ck, ld[ick], std::fabs(qq));
+            if (davidson_type & DavidsonTypes::DavidsonPrecond) // davidson_precondition (:66-72)
+                check(b2x_vec_precondition(q, aa_dev, ld[ick], n, nullptr));
+            else if (!(davidson_type & DavidsonTypes::NoPrecond)) { // olsen_precondition (:93-108)
+                check(b2x_vec_olsen_prepare(q, t, bs[ick], aa_dev, ld[ick], n, nullptr));
+                double cq = dot(bs[ick], q), ct = dot(bs[ick], t);
                 check(b2x_vec_axpy(-cq / ct, t, q, n, nullptr));
             }
             eigvals.resize(ck + 1);
             for (int i = 0; i <= ck; i++)
-                eigvals[i] = ld[i];
-            if (std::fabs(qq) < conv_thrd && m >= k) {
+                eigvals[i] = ld[idx[i]];
+            if (std::fabs(qq) < thrd(eigvals[ck]) && m >= k) {
                 ck++;
                 if (ck == k)
                     break;
             } else {
-                if (m >= deflation_max_size)
+                if (m >= deflation_max_size) {
                     m = msig = deflation_min_size;
+                    if ((davidson_type & DavidsonTypes::LessThan) || (davidson_type & DavidsonTypes::GreaterThan) ||
+                        (davidson_type & DavidsonTypes::CloseTo)) { // keep the roots that lead the chosen order (:1113-1141)
+                        for (int j = 0; j < m; j++) {
+                            check(b2x_vec_copy(bs[idx[j]], tb[j], n, nullptr));
+                            check(b2x_vec_copy(sg[idx[j]], ts[j], n, nullptr));
+                        }
+                        for (int j = 0; j < m; j++)
+                            std::swap(bs[j], tb[j]), std::swap(sg[j], ts[j]), idx[j] = j;
+                    }
+                }
                 for (int j = 0; j < m; j++)
                     check(b2x_vec_axpy(-dot(bs[j], q), bs[j], q, n, nullptr));
+                project_ors(q);
                 check(b2x_vec_scal(1.0 / std::sqrt(dot(q, q)), q, n, nullptr));
                 ensure(m);
                 check(b2x_vec_copy(q, bs[m], n, nullptr));
@@ -740,10 +847,35 @@ struct IterativeMatrixFunctions {
         if (xiter == max_iter)
             throw std::runtime_error("Davidson: only " + std::to_string(ck) + " converged!");
         for (int i = 0; i < k; i++)
-            check(b2x_vec_copy(bs[i], vs_dev[i], n, nullptr));
+            check(b2x_vec_copy(bs[idx[i]], vs_dev[i], n, nullptr));
+        if (pcomm != nullptr)
+            for (int i = 0; i < k; i++)
+                pcomm->broadcast(vs_dev[i], n);
         check(b2x_device_sync());
         ndav = xiter;
         return eigvals;
+    }
+    // the entry point EffectiveHamiltonian::eigs calls (:1181-1194): Harmonic types have their own solver in the
+    // reference, every other type is davidson()
+    static std::vector<double> harmonic_davidson(const std::function<void(const double *, double *)> &op,
+                                                 const double *aa_dev, std::vector<double *> &vs_dev, size_t n,
+                                                 double shift, DavidsonTypes davidson_type, int &ndav,
+                                                 bool iprint = false, const DeviceComm *pcomm = nullptr,
+                                                 double conv_thrd = 5E-6, double rel_conv_thrd = 0.0,
+                                                 int max_iter = 5000, int soft_max_iter = -1,
+                                                 int deflation_min_size = 2, int deflation_max_size = 50,
+                                                 const std::vector<double *> &ors = std::vector<double *>(),
+                                                 const std::vector<double> &proj_weights = std::vector<double>()) {
+        return davidson(op, aa_dev, vs_dev, n, shift, davidson_type, ndav, iprint, pcomm, conv_thrd, rel_conv_thrd,
+                        max_iter, soft_max_iter, deflation_min_size, deflation_max_size, ors, proj_weights);
+    }
+    // the round-1 call form (Normal type, no shift, no projection)
+    static std::vector<double> davidson(const std::function<void(const double *, double *)> &op, const double *aa_dev,
+                                        std::vector<double *> &vs_dev, size_t n, int &ndav, double conv_thrd = 5E-6,
+                                        int max_iter = 5000, int soft_max_iter = -1, int deflation_min_size = 2,
+                                        int deflation_max_size = 50, bool iprint = false) {
+        return davidson(op, aa_dev, vs_dev, n, 0.0, DavidsonTypes::Normal, ndav, iprint, nullptr, conv_thrd, 0.0,
+                        max_iter, soft_max_iter, deflation_min_size, deflation_max_size);
     }
 };
 
@@ -763,22 +895,38 @@ struct EffectiveHamiltonian {
         precompute();
         (*seq)(b, c, factor);
     }
-    std::tuple<double, int, size_t, double> eigs(std::vector<double> &ket, double conv_thrd = 5E-6, int max_iter = 5000,
-                                                 int soft_max_iter = -1, int deflation_min_size = 2,
-                                                 int deflation_max_size = 50, bool iprint = false) {
+    // eigs (effective_hamiltonian.hpp:470-558), arguments in the reference's order after ket (the reference takes ket
+    // from the object): ortho_bra = states projected out, projection_weights as in davidson; pcomm = para_rule->comm.
+    std::tuple<double, int, size_t, double> eigs(std::vector<double> &ket, bool iprint = false, double conv_thrd = 5E-6,
+                                                 double rel_conv_thrd = 0.0, int max_iter = 5000, int soft_max_iter = -1,
+                                                 int deflation_min_size = 2, int deflation_max_size = 50,
+                                                 DavidsonTypes davidson_type = DavidsonTypes::Normal, double shift = 0,
+                                                 const DeviceComm *pcomm = nullptr,
+                                                 const std::vector<std::vector<double>> &ortho_bra =
+                                                     std::vector<std::vector<double>>(),
+                                                 const std::vector<double> &projection_weights = std::vector<double>()) {
         if (ket.size() != n)
             throw std::runtime_error("EffectiveHamiltonian::eigs: ket length differs from diag");
         precompute();
         seq->cumulative_nflop = 0;
         DeviceVector dk(n), dd(n);
         dk.upload(ket.data()), dd.upload(diag.data());
+        std::vector<std::unique_ptr<DeviceVector>> dors;
+        std::vector<double *> ors;
+        for (auto &o : ortho_bra) {
+            if (o.size() != n)
+                throw std::runtime_error("EffectiveHamiltonian::eigs: ortho_bra length differs from diag");
+            dors.emplace_back(new DeviceVector(n));
+            dors.back()->upload(o.data());
+            ors.push_back(dors.back()->p);
+        }
         std::vector<double *> vs{dk.p};
         int ndav = 0;
         auto t0 = std::chrono::steady_clock::now();
         auto f = [this](const double *b, double *s) { seq->apply_device(b, s, 1.0); };
-        std::vector<double> eners = IterativeMatrixFunctions::davidson(f, dd.p, vs, n, ndav, conv_thrd, max_iter,
-                                                                       soft_max_iter, deflation_min_size,
-                                                                       deflation_max_size, iprint);
+        std::vector<double> eners = IterativeMatrixFunctions::harmonic_davidson(
+            f, dd.p, vs, n, shift, davidson_type, ndav, iprint, pcomm, conv_thrd, rel_conv_thrd, max_iter, soft_max_iter,
+            deflation_min_size, deflation_max_size, ors, projection_weights);
         double tdav = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         dk.download(ket.data());
         size_t nf = seq->cumulative_nflop;

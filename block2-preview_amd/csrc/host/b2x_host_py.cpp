@@ -46,6 +46,22 @@ struct PySeq : BatchGEMMSeq {
 
 PYBIND11_MODULE(b2x_host, m) {
     m.doc() = "C++ host mirror of block2's H.psi interface over the MI355X C ABI (include/b2x.h)";
+    py::enum_<DavidsonTypes>(m, "DavidsonTypes", py::arithmetic()) // pybind_core.hpp (same names / values)
+        .value("Normal", DavidsonTypes::Normal)
+        .value("GreaterThan", DavidsonTypes::GreaterThan)
+        .value("LessThan", DavidsonTypes::LessThan)
+        .value("CloseTo", DavidsonTypes::CloseTo)
+        .value("Harmonic", DavidsonTypes::Harmonic)
+        .value("HarmonicGreaterThan", DavidsonTypes::HarmonicGreaterThan)
+        .value("HarmonicLessThan", DavidsonTypes::HarmonicLessThan)
+        .value("HarmonicCloseTo", DavidsonTypes::HarmonicCloseTo)
+        .value("DavidsonPrecond", DavidsonTypes::DavidsonPrecond)
+        .value("NoPrecond", DavidsonTypes::NoPrecond)
+        .value("NonHermitian", DavidsonTypes::NonHermitian)
+        .value("Exact", DavidsonTypes::Exact)
+        .value("LeftEigen", DavidsonTypes::LeftEigen)
+        .value("ElementProj", DavidsonTypes::ElementProj)
+        .def("__or__", [](DavidsonTypes a, DavidsonTypes b) { return a | b; });
     py::enum_<SeqTypes>(m, "SeqTypes", py::arithmetic())
         .value("Nothing", SeqTypes::None)
         .value("Simple", SeqTypes::Simple)
@@ -209,35 +225,70 @@ PYBIND11_MODULE(b2x_host, m) {
                  h(GMatrix(b.mutable_data(), (int)b.size(), 1), GMatrix(c.mutable_data(), (int)c.size(), 1), factor);
              },
              py::arg("b"), py::arg("c"), py::arg("factor") = 1.0)
-        // eigs(ket, conv_thrd, max_iter, soft_max_iter, deflation_min_size, deflation_max_size, iprint)
-        //   -> (energy, ndav, nflop, tdav, ket_out)
+        // eigs(ket, ...) -> (energy, ndav, nflop, tdav, ket_out); keywords as the reference's eigs
+        // (effective_hamiltonian.hpp:471-480); ortho_bra = host vectors of |psi| doubles
         .def("eigs",
              [](EffectiveHamiltonian &h, std::vector<double> ket, double conv_thrd, int max_iter, int soft_max_iter,
-                int deflation_min_size, int deflation_max_size, bool iprint) {
-                 auto r = h.eigs(ket, conv_thrd, max_iter, soft_max_iter, deflation_min_size, deflation_max_size, iprint);
+                int deflation_min_size, int deflation_max_size, bool iprint, double rel_conv_thrd,
+                DavidsonTypes davidson_type, double shift, std::vector<std::vector<double>> ortho_bra,
+                std::vector<double> projection_weights) {
+                 auto r = h.eigs(ket, iprint, conv_thrd, rel_conv_thrd, max_iter, soft_max_iter, deflation_min_size,
+                                 deflation_max_size, davidson_type, shift, nullptr, ortho_bra, projection_weights);
                  return py::make_tuple(std::get<0>(r), std::get<1>(r), std::get<2>(r), std::get<3>(r),
                                        py::array_t<double>(ket.size(), ket.data()));
              },
              py::arg("ket"), py::arg("conv_thrd") = 5E-6, py::arg("max_iter") = 5000, py::arg("soft_max_iter") = -1,
-             py::arg("deflation_min_size") = 2, py::arg("deflation_max_size") = 50, py::arg("iprint") = false);
+             py::arg("deflation_min_size") = 2, py::arg("deflation_max_size") = 50, py::arg("iprint") = false,
+             py::arg("rel_conv_thrd") = 0.0, py::arg("davidson_type") = DavidsonTypes::Normal, py::arg("shift") = 0.0,
+             py::arg("ortho_bra") = std::vector<std::vector<double>>(),
+             py::arg("projection_weights") = std::vector<double>());
     // Davidson on a plan that is already resident on the device (a b2x_plan* from the C ABI, e.g. capi.Plan._h.value):
-    // diag and ket are device addresses of n doubles; ket is overwritten with the eigenvector.  Nothing but the
-    // Rayleigh-Ritz scalars crosses PCIe.  -> (eigenvalue, number of H.psi applications)
+    // diag, kets and ors are device addresses of n doubles; the kets are overwritten with the eigenvectors.  Nothing but
+    // the Rayleigh-Ritz scalars crosses PCIe.  comm = (b2x_comm*, rank, size, root) of the sum-MPO communicator: sigma is
+    // all-reduced after every H.psi and new basis vectors are broadcast from root, as the reference's davidson does
+    // with its pcomm.  -> (eigenvalue[s], number of H.psi applications)
     m.def("davidson_device",
-          [](uintptr_t plan, uintptr_t diag_dev, uintptr_t ket_dev, size_t n, double conv_thrd, int max_iter, int soft_max_iter,
-             int deflation_min_size, int deflation_max_size, bool iprint) {
+          [](uintptr_t plan, uintptr_t diag_dev, py::object ket_dev, size_t n, double conv_thrd, int max_iter, int soft_max_iter,
+             int deflation_min_size, int deflation_max_size, bool iprint, double rel_conv_thrd, DavidsonTypes davidson_type,
+             double shift, std::vector<uintptr_t> ors, std::vector<double> proj_weights, py::object comm) -> py::object {
               b2x_plan *p = (b2x_plan *)plan;
-              auto f = [p](const double *b, double *s) { check(b2x_plan_execute(p, b, s, 1.0, 1, nullptr)); };
-              std::vector<double *> vs{(double *)ket_dev};
+              DeviceComm dc;
+              const bool para = !comm.is_none();
+              if (para) {
+                  py::tuple t = comm.cast<py::tuple>();
+                  dc.comm = (b2x_comm *)t[0].cast<uintptr_t>();
+                  dc.rank = t[1].cast<int>(), dc.size = t[2].cast<int>(), dc.root = t[3].cast<int>();
+              }
+              size_t slen = n;
+              auto f = [p, para, dc, slen](const double *b, double *s) {
+                  check(b2x_plan_execute(p, b, s, 1.0, 1, nullptr));
+                  if (para) // ParallelTensorFunctions::operator() (parallel_tensor_functions.hpp:51-55)
+                      check(b2x_allreduce_sum(dc.comm, s, slen, nullptr));
+              };
+              const bool many = py::isinstance<py::sequence>(ket_dev);
+              std::vector<double *> vs;
+              if (many)
+                  for (auto h : ket_dev.cast<py::sequence>())
+                      vs.push_back((double *)h.cast<uintptr_t>());
+              else
+                  vs.push_back((double *)ket_dev.cast<uintptr_t>());
+              std::vector<double *> o;
+              for (auto x : ors)
+                  o.push_back((double *)x);
               int ndav = 0;
-              std::vector<double> e = IterativeMatrixFunctions::davidson(f, (const double *)diag_dev, vs, n, ndav, conv_thrd,
-                                                                         max_iter, soft_max_iter, deflation_min_size,
-                                                                         deflation_max_size, iprint);
+              std::vector<double> e = IterativeMatrixFunctions::harmonic_davidson(
+                  f, (const double *)diag_dev, vs, n, shift, davidson_type, ndav, iprint, para ? &dc : nullptr, conv_thrd,
+                  rel_conv_thrd, max_iter, soft_max_iter, deflation_min_size, deflation_max_size, o, proj_weights);
+              if (many)
+                  return py::make_tuple(e, ndav);
               return py::make_tuple(e[0], ndav);
           },
           py::arg("plan"), py::arg("diag_dev"), py::arg("ket_dev"), py::arg("n"), py::arg("conv_thrd") = 5E-6,
           py::arg("max_iter") = 5000, py::arg("soft_max_iter") = -1, py::arg("deflation_min_size") = 2,
-          py::arg("deflation_max_size") = 50, py::arg("iprint") = false);
+          py::arg("deflation_max_size") = 50, py::arg("iprint") = false, py::arg("rel_conv_thrd") = 0.0,
+          py::arg("davidson_type") = DavidsonTypes::Normal, py::arg("shift") = 0.0,
+          py::arg("ors") = std::vector<uintptr_t>(), py::arg("proj_weights") = std::vector<double>(),
+          py::arg("comm") = py::none());
     b2xh::bind_symbolic(m);
     m.def("device_init", [](int ordinal) { check(b2x_device_init(ordinal)); }, py::arg("ordinal") = 0);
     m.def("small_eigs", [](std::vector<double> a, int n) {

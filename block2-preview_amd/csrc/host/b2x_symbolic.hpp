@@ -889,7 +889,7 @@ template <typename S> struct SymbolicEffectiveHamiltonian {
                                                  int deflation_max_size = 50) {
         precompute();
         EffectiveHamiltonian h(tf->opf->seq, diag);
-        return h.eigs(ket, conv_thrd, max_iter, soft_max_iter, deflation_min_size, deflation_max_size);
+        return h.eigs(ket, false, conv_thrd, 0.0, max_iter, soft_max_iter, deflation_min_size, deflation_max_size);
     }
 };
 

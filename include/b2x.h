@@ -236,8 +236,8 @@ int b2x_vec_axpy(double a, const double *x, double *y, size_t n, void *stream); 
 int b2x_vec_scal(double a, double *x, size_t n, void *stream);
 int b2x_vec_copy(const double *x, double *y, size_t n, void *stream);
 int b2x_vec_zero(double *x, size_t n, void *stream);
-/* Olsen/diagonal preconditioner step of davidson (iterative_matrix_functions.hpp:1084-1087):
- * q[i] /= (diag[i] - shift) when |diag[i]-shift| > 1e-12 */
+/* davidson_precondition (iterative_matrix_functions.hpp:66-72, used at :1084-1085 for DavidsonTypes::DavidsonPrecond):
+ * q[i] /= (shift - diag[i]) when |shift - diag[i]| > 1e-12   (shift = the current Ritz value ld) */
 int b2x_vec_precondition(double *q, const double *diag, double shift, size_t n, void *stream);
 /* first half of olsen_precondition (iterative_matrix_functions.hpp:93-108): t = c; then, where
  * |ld - diag[i]| > 1e-12:  t[i] /= ld - diag[i],  q[i] /= ld - diag[i].  (The caller finishes with

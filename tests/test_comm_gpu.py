@@ -51,6 +51,28 @@ def test_rccl_communicator_single_rank(gpu, tmp_path):
     c2.close(), comm.close(), d.close()
 
 
+def test_davidson_with_communicator(gpu, tmp_path):
+    """davidson with pcomm (iterative_matrix_functions.hpp:968-970, 1162-1167) on the device: sigma all-reduced after
+    every H.psi, new basis vectors and the result broadcast from root — real RCCL calls on a one-rank communicator —
+    gives the eigenpair of the run without a communicator."""
+    from block2_preview_amd import b2x_host
+    from block2_preview_amd.planfile import read_plan
+
+    pf = read_plan(os.path.join(GOLDEN, "n2su2.sw2.site5.plan"))
+    arena = gpu.Arena.from_host([pf.arena])
+    plan = gpu.Plan(arena, pf.pairs, pf.psi_len, pf.sigma_len)
+    diag = gpu.DeviceBuffer(pf.psi_len, pf.diag)
+    comm = gpu.Comm(0, 1, id_file=str(tmp_path / "id"))
+    res = []
+    for c in (None, (comm._h.value, 0, 1, 0)):
+        ket = gpu.DeviceBuffer(pf.psi_len, pf.psi)
+        e, nd = b2x_host.davidson_device(plan._h.value, diag.ptr, ket.ptr, pf.psi_len, 1e-12, 500, comm=c)
+        res.append((e, nd, ket.download()))
+        ket.close()
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1] and np.array_equal(res[0][2], res[1][2])
+    comm.close(), diag.close(), plan.close(), arena.close()
+
+
 def _spawn(world, shard, fns, two_stage=0):
     port = str(_free_port())
     env = dict(os.environ, B2X_TEST_TWO_STAGE=str(two_stage))

@@ -143,3 +143,82 @@ def test_eigs_matches_dense_diagonalisation(host):
     e, ndav, _, _, ket = h.eigs(pf.psi.tolist(), conv_thrd=1e-14, max_iter=300)
     assert abs(e - w[0]) < 1e-10
     assert np.abs(H @ ket - e * ket).max() < 1e-6
+
+
+def _dense_case(host):
+    from block2_preview_amd import capi
+
+    pf = read_plan(os.path.join(GOLDEN, "n2su2.sw2.site5.plan"))
+    H = oracle.dense(pf.pairs, pf.arena, pf.psi_len, pf.sigma_len)
+    H = 0.5 * (H + H.T)
+    w, v = np.linalg.eigh(H)
+    return capi, pf, H, w, v
+
+
+def test_davidson_types_shift_and_rel_thrd(host):
+    """davidson_type / shift select the roots as the reference orders them (iterative_matrix_functions.hpp:1024-1049):
+    CloseTo -> nearest to shift, LessThan -> largest eigenvalue <= shift, GreaterThan -> smallest >= shift; the
+    DavidsonPrecond / NoPrecond variants (:1084-1087) reach the same ground state; rel_conv_thrd loosens the stop test."""
+    capi, pf, H, w, v = _dense_case(host)
+    DT = host.DavidsonTypes
+    seq = host.BatchGEMMSeq()
+    seq.load_pairs(pf.pairs, pf.arena)
+    h = host.EffectiveHamiltonian(seq, pf.diag.tolist())
+    rng = np.random.default_rng(3)
+    shift = 0.5 * (w[3] + w[4]) + 0.1 * (w[4] - w[3])  # between the 4th and 5th level, nearer to the 5th
+    for typ, want in ((DT.CloseTo, w[4]), (DT.LessThan, w[3]), (DT.GreaterThan, w[4])):
+        # guess = target eigenvector + noise (interior roots from a random guess need many iterations)
+        tgt = v[:, int(np.argmin(np.abs(w - want)))]
+        g = tgt + 0.02 * rng.standard_normal(len(tgt)) / np.sqrt(len(tgt))  # Ritz value of the guess on the right side of shift
+        e, ndav, _, _, ket = h.eigs(g.tolist(), conv_thrd=1e-12, max_iter=2000, davidson_type=typ, shift=shift)
+        assert abs(e - want) < 1e-8, (typ, e, want, ndav)
+        assert np.abs(H @ ket - e * ket).max() < 1e-5
+    nd = {}
+    for typ in (DT.Normal, DT.DavidsonPrecond, DT.NoPrecond):
+        e, nd[typ], _, _, ket = h.eigs(pf.psi.tolist(), conv_thrd=1e-12, max_iter=2000, davidson_type=typ)
+        assert abs(e - w[0]) < 1e-9, (typ, e, w[0])
+    g0 = (v[:, 0] + 0.3 * rng.standard_normal(len(w)) / np.sqrt(len(w))).tolist()
+    e_tight, nd_tight, _, _, _ = h.eigs(g0, conv_thrd=1e-14, max_iter=2000)
+    e_loose, nd_loose, _, _, _ = h.eigs(g0, conv_thrd=1e-14, rel_conv_thrd=1e-4, max_iter=2000)
+    assert nd_loose < nd_tight and abs(e_loose - w[0]) < 1e-4 and abs(e_tight - w[0]) < 1e-10  # |r|^2 < thrd + (E rel)^2
+    with pytest.raises(RuntimeError):
+        h.eigs(pf.psi.tolist(), davidson_type=DT.Harmonic)
+    h.post_precompute()
+
+
+def test_davidson_projects_out_ortho_states(host):
+    """ors / proj_weights (iterative_matrix_functions.hpp:888-893, 946-959, 975-977): with the ground state projected
+    out ((1 - |v><v|)) or shifted up (H + w |v><v|) Davidson returns the first excited state."""
+    capi, pf, H, w, v = _dense_case(host)
+    seq = host.BatchGEMMSeq()
+    seq.load_pairs(pf.pairs, pf.arena)
+    h = host.EffectiveHamiltonian(seq, pf.diag.tolist())
+    gs = v[:, 0]
+    rng = np.random.default_rng(5)
+    g = (v[:, 1] + 0.1 * rng.standard_normal(len(gs)) / np.sqrt(len(gs))).tolist()
+    e, ndav, _, _, ket = h.eigs(g, conv_thrd=1e-12, max_iter=2000, ortho_bra=[(2.5 * gs).tolist()])
+    assert abs(e - w[1]) < 1e-8 and abs(ket @ gs) < 1e-8
+    e2, _, _, _, ket2 = h.eigs(g, conv_thrd=1e-12, max_iter=2000, ortho_bra=[gs.tolist()],
+                               projection_weights=[w[-1] - w[0] + 1.0])
+    assert abs(e2 - w[1]) < 1e-8 and abs(ket2 @ gs) < 1e-6
+    h.post_precompute()
+
+
+def test_vec_precondition_is_the_reference_formula(host):
+    """davidson_precondition (iterative_matrix_functions.hpp:66-72): q[i] /= ld - aa[i] where |ld - aa[i]| > 1e-12."""
+    from block2_preview_amd import capi
+
+    rng = np.random.default_rng(11)
+    n = 10007
+    q, aa = rng.standard_normal(n), rng.standard_normal(n)
+    ld = 0.3
+    aa[5] = ld  # untouched element
+    import ctypes as C
+
+    dq, da = capi.DeviceBuffer(n, q), capi.DeviceBuffer(n, aa)
+    capi.check(capi.lib().b2x_vec_precondition(C.c_void_p(dq.ptr), C.c_void_p(da.ptr), C.c_double(ld), C.c_size_t(n), None))
+    ref = q.copy()
+    m = np.abs(ld - aa) > 1e-12
+    ref[m] /= ld - aa[m]
+    out = dq.download()
+    assert out[5] == q[5] and np.abs(out - ref).max() <= 4e-16 * np.abs(ref).max()
