@@ -338,6 +338,10 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
     // the A half of a fetch: this wave's share of the LDS-DMA of the chunk at k offset kb into LDS buffer `As`
     auto fetch_dma = [&](int kb, double *As) __attribute__((always_inline)) {
         const char *ba = (const char *)(sA + (uint64_t)((uint32_t)kb * astep));
+#ifdef B2X_PROBE_NO_LOADS // (timing probe, wrong results)
+        if (kb != 0x7fffffff)
+            return;
+#endif
 #pragma unroll
         for (int j = 0; j < NI; j++)
             if (NG % NT == 0 || (wave * NI + j) * 64 < NG) // whole DMA instruction inside the image
@@ -354,7 +358,11 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
         for (int s = 0; s < KS; s++) {
 #pragma unroll
             for (int q = 0; q < CF; q++)
+#ifdef B2X_PROBE_NO_LOADS
+                bnxt[q][s] = (double)(vb[q][s] & 1);
+#else
                 bnxt[q][s] = *(const double *)(bb + vb[q][s]);
+#endif
             bb += b_s4;
         }
     };
@@ -413,6 +421,10 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
         for (int s = 0; s < NS; s++)
 #pragma unroll
             for (int f = 0; f < TMF; f++) {
+#ifdef B2X_PROBE_ONE_FRAG // (timing probe, wrong results: `make probes`, tools/probe_ab.sh)
+                if (f > 0)
+                    continue;
+#endif
                 double a = pb[s][f * 16 * KC];
 #pragma unroll
                 for (int q = 0; q < CF; q++)

@@ -7,6 +7,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <numeric>
+#include <unordered_map>
 
 namespace b2x {
 
@@ -460,6 +461,26 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             ss.sum_begin = (uint32_t)out.sum_work.size();
             uint64_t sum_extra = 0; // scratch taken by the sums of this step, behind its W slots
             const uint32_t s0_begin = (uint32_t)out.gitems.size();
+            // Locality key of a stage-0 item (s0_order below).  The products that read one B operand — X_i . op(Y) for the
+            // psi slices X_i that meet one right-operator block Y, op(Z_i) . X for the left-operator blocks that meet one
+            // psi slice X — are the row blocks of ONE tall product [X_1; X_2; ...] . op(Y): its tiles of one column read the
+            // same B tile, those of one row the same A rows.  key = (B operand, 4 x 4 block of tiles of that tall product).
+            std::vector<uint64_t> s0_key;
+            struct BGroup {
+                uint32_t id, row_tiles;
+            };
+            std::unordered_map<uint64_t, BGroup> bgroups;
+            auto s0_group = [&](uint64_t b_id, size_t n_row_tiles) -> BGroup {
+                auto it = bgroups.find(b_id);
+                if (it == bgroups.end())
+                    it = bgroups.emplace(b_id, BGroup{(uint32_t)bgroups.size(), 0u}).first;
+                BGroup r = it->second;
+                it->second.row_tiles += (uint32_t)n_row_tiles;
+                return r;
+            };
+            auto s0_push_key = [&](const BGroup &bg, size_t a, size_t b) {
+                s0_key.push_back(((uint64_t)bg.id << 24) | ((uint64_t)(((bg.row_tiles + a) / 4) & 0xFFF) << 12) | (uint64_t)((b / 4) & 0xFFF));
+            };
             // stage 0: tiles of every W
             for (const PW &pw : cur) {
                 const b2x_pair &p = ep[win[pw.wi].pair];
@@ -467,8 +488,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     continue;
                 if (pw.flip) { // W'(m1 x k0) = op(Z)(m1 x k1) . X(k1 x k0)
                     std::vector<int> rc = unit_cuts(p.m1), cc = wave_cuts(p.k0, TN);
+                    const BGroup bg = s0_group(((uint64_t)1 << 63) | p.x_off, rc.size() - 1);
                     for (size_t a = 0; a + 1 < rc.size(); a++)
                         for (size_t b = 0; b + 1 < cc.size(); b++) {
+                            s0_push_key(bg, a, b);
                             GSeg g{};
                             g.a_src = zsrc[win[pw.wi].pair];
                             if (p.ta1)
@@ -489,8 +512,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     continue;
                 }
                 std::vector<int> rc = unit_cuts(p.k1), cc = wave_cuts(p.n0, TN);
+                const BGroup bg = s0_group(((uint64_t)ysrc[win[pw.wi].pair] << 62) | p.y_off, rc.size() - 1);
                 for (size_t a = 0; a + 1 < rc.size(); a++)
                     for (size_t b = 0; b + 1 < cc.size(); b++) {
+                        s0_push_key(bg, a, b);
                         GSeg g{};
                         g.a_src = 1, g.a_off = p.x_off + (uint64_t)rc[a] * p.lda0, g.a_sr = p.lda0, g.a_sk = 1;
                         g.b_src = ysrc[win[pw.wi].pair];
@@ -710,8 +735,6 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     k += (uint64_t)round_up(out.gsegs[q].K, 16);
                 return k * (uint64_t)(variant(x) + 1);
             };
-            auto order = [&](const GItem &x, const GItem &y) { return icost(x) > icost(y); };
-            std::stable_sort(out.gitems.begin() + s0_begin, out.gitems.begin() + s1_begin, order);
             // tall tiles first, short ones (<= kGGShortFrags row fragments) behind them: each class is one launch of the
             // kernel instantiation that serves it (launch_gg); the cost order holds inside a class
             // The short class gets its own launch (on the plan's auxiliary stream, beside the tall one: launch_stage in
@@ -731,10 +754,82 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             static const double thr = getenv("B2X_SPLIT_THR") ? atof(getenv("B2X_SPLIT_THR")) : 0.3;
             const bool split0 = short_share(s0_begin, s1_begin) >= thr, split1 = short_share(s1_begin, s1_end) >= thr;
             auto tall = [](const GItem &x) { return x.rows > kGGShortFrags * kGGRowUnit; };
-            const uint32_t s0_mid = !split0 ? s1_begin
-                                            : (uint32_t)(std::stable_partition(out.gitems.begin() + s0_begin,
-                                                                               out.gitems.begin() + s1_begin, tall) -
-                                                         out.gitems.begin());
+            // Stage 0: one workgroup per W tile.  Workgroup ids i, i + 8, i + 16, ... run on one XCD (one L2, whose lines
+            // live a few microseconds under this traffic): the items of a locality group (s0_key) are handed to ONE XCD as
+            // consecutive workgroups, so that all but the first find their B tile / A rows in that L2.  Groups go
+            // longest first to the XCD queue with the least work so far (tail balance as before); B2X_S0_LOCAL=0 restores
+            // the plain longest-first order.
+            uint32_t s0_mid = s1_begin;
+            {
+                const uint32_t n0 = s1_begin - s0_begin;
+                static const int s0_local = getenv("B2X_S0_LOCAL") ? atoi(getenv("B2X_S0_LOCAL")) : 1;
+                struct IK {
+                    uint64_t cost, grp;
+                    uint32_t idx;
+                    bool tall;
+                };
+                std::vector<IK> ik(n0);
+                for (uint32_t q = 0; q < n0; q++) {
+                    const GItem &it = out.gitems[s0_begin + q];
+                    ik[q] = IK{icost(it), s0_key[q], s0_begin + q, !split0 || tall(it)};
+                }
+                std::vector<GItem> sorted;
+                sorted.reserve(n0);
+                for (int cl = 0; cl < 2; cl++) { // tall class, then the short one (its own launch when split0)
+                    std::vector<IK> v;
+                    for (const IK &k : ik)
+                        if (k.tall == (cl == 0))
+                            v.push_back(k);
+                    if (cl == 0)
+                        s0_mid = s0_begin + (uint32_t)v.size();
+                    if (!s0_local || v.size() < 64) {
+                        std::stable_sort(v.begin(), v.end(), [](const IK &x, const IK &y) { return x.cost > y.cost; });
+                        for (const IK &k : v)
+                            sorted.push_back(out.gitems[k.idx]);
+                        continue;
+                    }
+                    // groups: members together (longest first inside), groups by their longest member
+                    std::stable_sort(v.begin(), v.end(), [](const IK &x, const IK &y) {
+                        return x.grp != y.grp ? x.grp < y.grp : x.cost > y.cost;
+                    });
+                    struct Grp {
+                        uint64_t maxc, sum;
+                        uint32_t b, e;
+                    };
+                    std::vector<Grp> gs;
+                    for (uint32_t a = 0; a < v.size();) {
+                        uint32_t b = a;
+                        uint64_t sum = 0;
+                        while (b < v.size() && v[b].grp == v[a].grp)
+                            sum += v[b].cost + 64, b++; // (+64: a workgroup's fixed cost in the same MFMA-slot unit)
+                        gs.push_back(Grp{v[a].cost, sum, a, b});
+                        a = b;
+                    }
+                    std::stable_sort(gs.begin(), gs.end(), [](const Grp &x, const Grp &y) { return x.maxc > y.maxc; });
+                    const size_t N = v.size();
+                    std::vector<std::vector<uint32_t>> qu(8);
+                    size_t cap[8];
+                    uint64_t load[8] = {};
+                    for (size_t x = 0; x < 8; x++)
+                        cap[x] = (N - x + 7) / 8, qu[x].reserve(cap[x]);
+                    for (const Grp &g : gs) {
+                        uint32_t a = g.b;
+                        while (a < g.e) { // least-loaded queue with room; a group larger than the room is split
+                            int best = -1;
+                            for (int x = 0; x < 8; x++)
+                                if (qu[x].size() < cap[x] && (best < 0 || load[x] < load[best]))
+                                    best = x;
+                            const uint32_t take = (uint32_t)std::min<size_t>(g.e - a, cap[best] - qu[best].size());
+                            for (uint32_t q = a; q < a + take; q++)
+                                qu[best].push_back(v[q].idx), load[best] += v[q].cost + 64;
+                            a += take;
+                        }
+                    }
+                    for (size_t i = 0; i < N; i++)
+                        sorted.push_back(out.gitems[qu[i % 8][i / 8]]);
+                }
+                std::copy(sorted.begin(), sorted.end(), out.gitems.begin() + s0_begin);
+            }
             uint32_t s1_mid = s1_begin;
             // Stage 1: longest first ACROSS sibling groups, siblings together inside a group.  Items of equal cost that
             // take the same K range (item index j) of neighbouring tiles of one sector walk the same operands: the tiles of

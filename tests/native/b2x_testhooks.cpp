@@ -3,6 +3,8 @@
 // parts / items, the algebraic rewrites) against the oracle.  It links the host-only compiler source
 // (block2-preview_amd/csrc/b2x_plan.cpp) and nothing of the device path; it is NOT part of libb2x.so and nothing in the
 // product loads it.
+#include <cstdio>
+#include <cstdlib>
 #include "b2x_emulate.hpp"
 #include <algorithm>
 #include <cstring>
@@ -55,6 +57,29 @@ int b2x_debug_compile_and_emulate(size_t n_pairs, const b2x_pair *pairs, size_t 
         *fallback = cp.fallback ? 1 : 0;
     if (!cp.fallback && arena && psi && sigma)
         emulate_plan_host(cp, arena, psi, sigma, scale);
+    if (getenv("B2X_TEST_TRAFFIC_MODEL")) { // operand bytes the grouped-GEMM work list requests, per stage and source
+        double by[2][2][3] = {}, outb[2] = {};
+        uint64_t nit[2] = {}, nseg[2] = {}, chunks[2] = {};
+        for (const SuperStep &ss : cp.steps)
+            for (int stg = 0; stg < 2; stg++) {
+                const uint32_t *v = stg ? ss.s1_v : ss.s0_v;
+                for (uint32_t i = v[0]; i < v[kGGVariants]; i++) {
+                    const GItem &it = cp.gitems[i];
+                    nit[stg]++, outb[stg] += 8.0 * it.rows * it.cols;
+                    for (uint32_t sg = it.seg_begin; sg < it.seg_end; sg++) {
+                        const GSeg &g = cp.gsegs[sg];
+                        nseg[stg]++, chunks[stg] += (g.K + 15) / 16;
+                        by[stg][0][g.a_src] += 8.0 * it.rows * g.K;
+                        by[stg][1][g.b_src] += 8.0 * g.K * it.cols;
+                    }
+                }
+            }
+        for (int stg = 0; stg < 2; stg++)
+            fprintf(stderr, "stage %d: items %llu segs %llu chunks %llu | A arena %.3f psi %.3f scratch %.3f | B arena %.3f psi %.3f "
+                    "scratch %.3f | out %.3f GB\n", stg, (unsigned long long)nit[stg], (unsigned long long)nseg[stg],
+                    (unsigned long long)chunks[stg], by[stg][0][0] / 1e9, by[stg][0][1] / 1e9, by[stg][0][2] / 1e9,
+                    by[stg][1][0] / 1e9, by[stg][1][1] / 1e9, by[stg][1][2] / 1e9, outb[stg] / 1e9);
+    }
     return B2X_OK;
 }
 
