@@ -1,6 +1,5 @@
 #!/bin/bash
 # same-box timing of ablated builds of the kernel (WRONG results by construction; timing only): tools/probe_ab.sh workload...
-export B2X_S0_CHAIN=0
 for w in "$@"; do
   for l in "" probe_onefrag probe_noloads probe_neither; do
     if [ -n "$l" ]; then export B2X_LIB=$GRAFT_REPO_ROOT/block2-preview_amd/libb2x_$l.so; else unset B2X_LIB; fi
