@@ -78,6 +78,23 @@ struct b2x_plan {
     int dominant_cls = 0;
     bool seg_scaled = false; // single-GEMM list plan (gg_kernel SCALED variant)
     int gg_tile_n = 128;
+    // The launches of one H.psi as a HIP graph (device-pointer execute only): captured on first use, replayed with the
+    // psi / sigma / scale arguments of its kernel nodes patched per call.  An H.psi of a small plan is a handful of
+    // short kernels on two streams; launched one by one, the gaps between them (launch latency, the event fork / join of
+    // the two tile classes) are a tenth of its time.
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    struct GNode {
+        hipGraphNode_t node;
+        hipKernelNodeParams params; // kernelParams points into the graph's own copy of the arguments
+        int psi_slot, sigma_slot, scale_slot;
+    };
+    std::vector<GNode> gnodes;
+    const double *g_psi = nullptr;
+    double *g_sigma = nullptr;
+    double g_scale = 0;
+    bool graph_failed = false;
 };
 
 static void plan_free(b2x_plan *p) {
@@ -117,6 +134,12 @@ static void plan_free(b2x_plan *p) {
         (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join)
         (void)hipEventDestroy(p->ev_join);
+    if (p->gexec)
+        (void)hipGraphExecDestroy(p->gexec);
+    if (p->graph)
+        (void)hipGraphDestroy(p->graph);
+    if (p->cap_stream)
+        (void)hipStreamDestroy(p->cap_stream);
     delete p;
 }
 
@@ -439,12 +462,89 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
     return B2X_OK;
 }
 
+// run_plan through a HIP graph (see b2x_plan::graph).  Returns B2X_OK after a graph launch, a negative value when the
+// graph path is not available for this plan (the caller launches directly).
+static const int kGraphUnavailable = -1000;
+static int run_plan_graph(b2x_plan *p, const double *psi, double *sigma, double scale, hipStream_t st) {
+    static const int enabled = getenv("B2X_GRAPH") ? atoi(getenv("B2X_GRAPH")) : 1;
+    if (!enabled || p->graph_failed || p->fallback || !p->stage_in.empty())
+        return kGraphUnavailable;
+    auto give_up = [&]() {
+        p->graph_failed = true;
+        (void)hipGetLastError();
+        return kGraphUnavailable;
+    };
+    if (!p->gexec) {
+        if (hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess)
+            return give_up();
+        if (!p->aux_stream) { // (created outside the capture: launch_stage would create them inside it)
+            HIPCHK(hipStreamCreateWithFlags(&p->aux_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+        }
+        if (hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+            return give_up();
+        int rc = run_plan(p, psi, sigma, scale, p->cap_stream);
+        hipError_t e = hipStreamEndCapture(p->cap_stream, &p->graph);
+        if (rc != B2X_OK || e != hipSuccess || !p->graph)
+            return give_up();
+        if (hipGraphInstantiate(&p->gexec, p->graph, nullptr, nullptr, 0) != hipSuccess) {
+            p->gexec = nullptr;
+            return give_up();
+        }
+        size_t nn = 0;
+        if (hipGraphGetNodes(p->graph, nullptr, &nn) != hipSuccess)
+            return give_up();
+        std::vector<hipGraphNode_t> nodes(nn);
+        if (nn && hipGraphGetNodes(p->graph, nodes.data(), &nn) != hipSuccess)
+            return give_up();
+        for (hipGraphNode_t nd : nodes) {
+            hipGraphNodeType ty;
+            if (hipGraphNodeGetType(nd, &ty) != hipSuccess)
+                return give_up();
+            if (ty != hipGraphNodeTypeKernel)
+                continue;
+            b2x_plan::GNode g{};
+            g.node = nd, g.psi_slot = g.sigma_slot = g.scale_slot = -1;
+            if (hipGraphKernelNodeGetParams(nd, &g.params) != hipSuccess || !g.params.kernelParams)
+                return give_up();
+            // every kernel of the path has at least four arguments; psi is argument 3 of the GEMM kernels
+            // (gg_kernel, hpsi_wave), (sigma, scale) are arguments 2 and 3 of hpsi_reduce
+            void **kp = g.params.kernelParams;
+            if (*(const double **)kp[3] == psi)
+                g.psi_slot = 3;
+            else if (*(double **)kp[2] == sigma)
+                g.sigma_slot = 2, g.scale_slot = 3;
+            p->gnodes.push_back(g);
+        }
+        p->g_psi = psi, p->g_sigma = sigma, p->g_scale = scale;
+    }
+    if (psi != p->g_psi || sigma != p->g_sigma || scale != p->g_scale) {
+        for (b2x_plan::GNode &g : p->gnodes) {
+            if (g.psi_slot < 0 && g.sigma_slot < 0)
+                continue;
+            void **kp = g.params.kernelParams; // the graph's own argument copies: patched in place, then re-submitted
+            if (g.psi_slot >= 0)
+                *(const double **)kp[g.psi_slot] = psi;
+            if (g.sigma_slot >= 0)
+                *(double **)kp[g.sigma_slot] = sigma, *(double *)kp[g.scale_slot] = scale;
+            if (hipGraphExecKernelNodeSetParams(p->gexec, g.node, &g.params) != hipSuccess)
+                return give_up();
+        }
+        p->g_psi = psi, p->g_sigma = sigma, p->g_scale = scale;
+    }
+    HIPCHK(hipGraphLaunch(p->gexec, st));
+    return B2X_OK;
+}
+
 int b2x_plan_execute(b2x_plan *p, const double *psi, double *sigma, double scale, int on_device, void *stream) {
     if (!p || !psi || !sigma)
         return fail(B2X_ERR_INVALID, "b2x_plan_execute: null argument");
     hipStream_t st = (hipStream_t)stream;
-    if (on_device)
-        return run_plan(p, psi, sigma, scale, st);
+    if (on_device) {
+        const int rc = run_plan_graph(p, psi, sigma, scale, st);
+        return rc == kGraphUnavailable ? run_plan(p, psi, sigma, scale, st) : rc;
+    }
     if (!p->d_psi)
         HIPCHK(hipMalloc((void **)&p->d_psi, (p->psi_len ? p->psi_len : 1) * sizeof(double)));
     if (!p->d_sigma)

@@ -74,6 +74,25 @@ int b2x_debug_compile_and_emulate(size_t n_pairs, const b2x_pair *pairs, size_t 
                     }
                 }
             }
+        for (int stg = 0; stg < 2; stg++) {
+            uint64_t n32 = 0, n64 = 0, nw = 0, c32 = 0, call = 0;
+            for (const SuperStep &ss : cp.steps) {
+                const uint32_t *v = stg ? ss.s1_v : ss.s0_v;
+                for (uint32_t i = v[0]; i < v[kGGVariants]; i++) {
+                    const GItem &it = cp.gitems[i];
+                    uint64_t ch = 0;
+                    for (uint32_t sg = it.seg_begin; sg < it.seg_end; sg++)
+                        ch += (cp.gsegs[sg].K + 15) / 16;
+                    (it.cols <= 32 ? n32 : it.cols <= 64 ? n64 : nw)++;
+                    call += ch;
+                    if (it.cols <= 32)
+                        c32 += ch;
+                }
+            }
+            fprintf(stderr, "stage %d: items with cols <= 32: %llu (chunks %llu of %llu), <= 64: %llu, wider: %llu\n", stg,
+                    (unsigned long long)n32, (unsigned long long)c32, (unsigned long long)call, (unsigned long long)n64,
+                    (unsigned long long)nw);
+        }
         for (int stg = 0; stg < 2; stg++)
             fprintf(stderr, "stage %d: items %llu segs %llu chunks %llu | A arena %.3f psi %.3f scratch %.3f | B arena %.3f psi %.3f "
                     "scratch %.3f | out %.3f GB\n", stg, (unsigned long long)nit[stg], (unsigned long long)nseg[stg],
