@@ -58,6 +58,59 @@ enum struct SeqTypes : uint8_t { None = 0, Simple = 1, Auto = 2, Tasked = 4, Sim
 // Plan recorder + device executor.  As in the reference, psi / psi' operands are recorded as OFFSETS
 // ("pointers from null": precompute() sets cmat->data = vmat->data = 0), operator operands as absolute
 // host pointers; the operator ranges are uploaded once, when the plan is first executed.
+// Threading (src/core/threading.hpp:105-135, 137-): the one field of the global threading scheme this path reads —
+// OperatorFunctions takes the mode of its sequence from it (src/core/operator_functions.hpp:73-75).
+struct Threading {
+    SeqTypes seq_type = SeqTypes::Device;
+};
+inline std::shared_ptr<Threading> &threading_() {
+    static std::shared_ptr<Threading> t = std::make_shared<Threading>();
+    return t;
+}
+
+// ParallelCommunicator<S> (src/core/parallel_rule.hpp:38-308): size / rank / root, tcomm, and the three collectives the
+// H.psi path uses, on DEVICE-resident fp64 vectors.  The base class is the serial communicator of the reference: its
+// collectives must not be called (the reference asserts false, :56-307).
+struct ParallelCommunicator {
+    int size, rank, root;
+    double tcomm = 0.0; // seconds spent in collectives
+    ParallelCommunicator(int size = 1, int rank = 0, int root = 0) : size(size), rank(rank), root(root) {}
+    virtual ~ParallelCommunicator() = default;
+    bool is_root() const { return rank == root; }
+    virtual void allreduce_sum(double *, size_t) { throw std::runtime_error("ParallelCommunicator::allreduce_sum: serial communicator"); }
+    virtual void broadcast(double *, size_t, int) { throw std::runtime_error("ParallelCommunicator::broadcast: serial communicator"); }
+    virtual void barrier() { throw std::runtime_error("ParallelCommunicator::barrier: serial communicator"); }
+    virtual b2x_comm *handle() const { return nullptr; }
+};
+// the MPICommunicator of this build (src/core/parallel_mpi.hpp:300-309, 133-141, 125-132): RCCL over xGMI through the C ABI
+struct RCCLCommunicator : ParallelCommunicator {
+    b2x_comm *comm = nullptr;
+    RCCLCommunicator(int rank, int size, const std::string &id_file, int root = 0) : ParallelCommunicator(size, rank, root) {
+        check(b2x_comm_init(&comm, rank, size, id_file.c_str()));
+    }
+    ~RCCLCommunicator() override {
+        if (comm)
+            b2x_comm_destroy(comm);
+    }
+    RCCLCommunicator(const RCCLCommunicator &) = delete;
+    RCCLCommunicator &operator=(const RCCLCommunicator &) = delete;
+    template <typename F> void timed(F f) {
+        auto t0 = std::chrono::steady_clock::now();
+        f();
+        tcomm += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+    void allreduce_sum(double *dev, size_t n) override {
+        timed([&]() { check(b2x_allreduce_sum(comm, dev, n, nullptr)); });
+    }
+    void broadcast(double *dev, size_t n, int owner) override {
+        timed([&]() { check(b2x_broadcast(comm, dev, n, owner, nullptr)); });
+    }
+    void barrier() override {
+        timed([&]() { check(b2x_barrier(comm)); });
+    }
+    b2x_comm *handle() const override { return comm; }
+};
+
 struct BatchGEMMSeq {
     SeqTypes mode = SeqTypes::Device;
     std::vector<b2x_pair> pairs;
@@ -67,7 +120,7 @@ struct BatchGEMMSeq {
     b2x_arena *arena = nullptr;
     b2x_plan *plan = nullptr;
     size_t psi_len = 0, sigma_len = 0;
-    BatchGEMMSeq(size_t /*max_batch_flops*/ = 1LL << 24, SeqTypes mode = SeqTypes::Device) : mode(mode) {}
+    BatchGEMMSeq(size_t /*max_batch_flops*/ = 1LL << 24, SeqTypes mode = threading_()->seq_type) : mode(mode) {}
     ~BatchGEMMSeq() { deallocate(); }
     BatchGEMMSeq(const BatchGEMMSeq &) = delete;
     BatchGEMMSeq &operator=(const BatchGEMMSeq &) = delete;
@@ -882,10 +935,23 @@ struct IterativeMatrixFunctions {
 // The local problem of one site at the level this path sees it: a recorded plan (what precompute() builds),
 // the diagonal and the wavefunction.  eigs() == EffectiveHamiltonian::eigs (effective_hamiltonian.hpp:470-558):
 // returns (energy, ndav, nflop, tdav); ket is overwritten with the eigenvector.
+// EffectiveKernel<FL> (effective_hamiltonian.hpp:81-91): a user hook AROUND the matrix-vector product f of eigs —
+// compute(beta, f, a, b, xs) must leave b += beta * H a (it may call f any number of times).  Here a, b (and xs) are
+// DEVICE vectors of |psi| doubles: Davidson never brings them to the host.
+struct EffectiveKernel {
+    typedef std::function<void(const double *, double *, double)> MatMul;
+    virtual ~EffectiveKernel() = default;
+    virtual void compute(double beta, const MatMul &f, const double *a, double *b, const std::vector<const double *> &xs) const {
+        (void)xs;
+        f(a, b, beta);
+    }
+};
+
 struct EffectiveHamiltonian {
     std::shared_ptr<BatchGEMMSeq> seq;
     std::vector<double> diag;
     size_t n;
+    std::shared_ptr<EffectiveKernel> eff_kernel; // (effective_hamiltonian.hpp:121, used at :515-519)
     EffectiveHamiltonian(const std::shared_ptr<BatchGEMMSeq> &seq, const std::vector<double> &diag)
         : seq(seq), diag(diag), n(diag.size()) {}
     void precompute() { seq->prepare(n, n); }
@@ -923,7 +989,13 @@ struct EffectiveHamiltonian {
         std::vector<double *> vs{dk.p};
         int ndav = 0;
         auto t0 = std::chrono::steady_clock::now();
-        auto f = [this](const double *b, double *s) { seq->apply_device(b, s, 1.0); };
+        EffectiveKernel::MatMul f3 = [this](const double *a, double *b, double scale) { seq->apply_device(a, b, scale); };
+        auto f = [this, &f3](const double *b, double *s) {
+            if (eff_kernel == nullptr)
+                f3(b, s, 1.0);
+            else
+                eff_kernel->compute(1.0, f3, b, s, std::vector<const double *>());
+        };
         std::vector<double> eners = IterativeMatrixFunctions::harmonic_davidson(
             f, dd.p, vs, n, shift, davidson_type, ndav, iprint, pcomm, conv_thrd, rel_conv_thrd, max_iter, soft_max_iter,
             deflation_min_size, deflation_max_size, ors, projection_weights);

@@ -44,6 +44,96 @@ struct PySeq : BatchGEMMSeq {
     using BatchGEMMSeq::BatchGEMMSeq;
 };
 
+// Python-overridable EffectiveKernel (src/pybind/pybind_dmrg.hpp:1107-1165): compute(beta, f, a, b, xs) with a, b, xs the
+// DEVICE addresses (int) of |psi| doubles and f(a, b, scale) the matrix-vector product b += scale * H a
+struct PyEffectiveKernel : EffectiveKernel {
+    void compute(double beta, const MatMul &f, const double *a, double *b, const std::vector<const double *> &xs) const override {
+        py::gil_scoped_acquire gil;
+        py::function over = py::get_override(static_cast<const EffectiveKernel *>(this), "compute");
+        if (!over) {
+            EffectiveKernel::compute(beta, f, a, b, xs);
+            return;
+        }
+        py::cpp_function pf([&f](uintptr_t pa, uintptr_t pb, double scale) { f((const double *)pa, (double *)pb, scale); });
+        std::vector<uintptr_t> px;
+        for (const double *x : xs)
+            px.push_back((uintptr_t)x);
+        over(beta, pf, (uintptr_t)a, (uintptr_t)b, px);
+    }
+};
+
+// Named classes of the hot path as block2's pybind exposes them per symmetry (src/pybind/pybind_core.hpp:1100-1340):
+// OperatorFunctions owns the sequence (mode from Global.threading.seq_type), TensorFunctions forwards operator() to it
+// (tensor_functions.hpp:59-62) and carries the symbolic walks; their inputs are the fixture dictionaries of
+// oracle/ref_dump.cpp, because OperatorTensor / SparseMatrixInfo objects are not bound as classes.
+template <typename S> struct PyOpf {
+    std::shared_ptr<PySeq> seq;
+};
+template <typename S> struct PyTf {
+    std::shared_ptr<PyOpf<S>> opf;
+    std::shared_ptr<ParallelCommunicator> comm; // ParallelTensorFunctions only
+    static bool is_right(const py::dict &d) { return SymEH<S>::template arr<uint64_t>(d, "meta")[2] != 0; }
+};
+template <typename S> static void bind_functions(py::module_ &m, const char *doc) {
+    py::module_ sm = m.def_submodule(std::is_same<S, SU2>::value ? "su2" : "sz", doc);
+    py::class_<PyOpf<S>, std::shared_ptr<PyOpf<S>>>(sm, "OperatorFunctions")
+        .def(py::init([](py::object seq) {
+                 auto o = std::make_shared<PyOpf<S>>();
+                 o->seq = seq.is_none() ? std::make_shared<PySeq>((size_t)1 << 24, threading_()->seq_type)
+                                        : seq.cast<std::shared_ptr<PySeq>>();
+                 return o;
+             }),
+             py::arg("seq") = py::none())
+        .def_readwrite("seq", &PyOpf<S>::seq);
+    auto call = [](PyTf<S> &t, py::array_t<double, py::array::c_style> b, py::array_t<double, py::array::c_style> c, double scale) {
+        BatchGEMMSeq &q = *t.opf->seq;
+        q.prepare((size_t)b.size(), (size_t)c.size());
+        if (t.comm == nullptr) { // TensorFunctions::operator() (tensor_functions.hpp:59-62)
+            q(GMatrix(b.mutable_data(), (int)b.size(), 1), GMatrix(c.mutable_data(), (int)c.size(), 1), scale);
+            return;
+        }
+        // ParallelTensorFunctions::operator() (parallel_tensor_functions.hpp:51-55): local H_r psi, then the all-reduce
+        DeviceVector db((size_t)b.size()), dc((size_t)c.size());
+        db.upload(b.data());
+        check(b2x_vec_zero(dc.p, (size_t)c.size(), nullptr));
+        q.apply_device(db.p, dc.p, scale);
+        t.comm->allreduce_sum(dc.p, (size_t)c.size());
+        std::vector<double> h((size_t)c.size());
+        dc.download(h.data());
+        for (py::ssize_t i = 0; i < c.size(); i++)
+            c.mutable_data()[i] += h[(size_t)i];
+    };
+    auto rot = [](bool want_right) {
+        return [want_right](PyTf<S> &, const py::dict &d, bool execute) {
+            if (PyTf<S>::is_right(d) != want_right)
+                throw std::runtime_error(want_right ? "right_rotate: the fixture is a left rotation" : "left_rotate: the fixture is a right rotation");
+            return sym_rotate<S>(d, execute);
+        };
+    };
+    py::class_<PyTf<S>, std::shared_ptr<PyTf<S>>>(sm, "TensorFunctions")
+        .def(py::init([](std::shared_ptr<PyOpf<S>> opf) {
+            auto t = std::make_shared<PyTf<S>>();
+            t->opf = opf;
+            return t;
+        }))
+        .def_readwrite("opf", &PyTf<S>::opf)
+        .def_readonly("comm", &PyTf<S>::comm)
+        .def("__call__", call, py::arg("b"), py::arg("c"), py::arg("scale") = 1.0)
+        .def("left_rotate", rot(false), py::arg("fixture"), py::arg("execute") = false)
+        .def("right_rotate", rot(true), py::arg("fixture"), py::arg("execute") = false)
+        .def("left_contract", [](PyTf<S> &, const py::dict &d, bool execute) { return sym_blocking<S>(d, execute); },
+             py::arg("fixture"), py::arg("execute") = false)
+        .def("right_contract", [](PyTf<S> &, const py::dict &d, bool execute) { return sym_blocking<S>(d, execute); },
+             py::arg("fixture"), py::arg("execute") = false)
+        .def("numerical_transform", [](PyTf<S> &, const py::dict &d) { return sym_transform<S>(d); }, py::arg("fixture"));
+    // ParallelTensorFunctions(opf, comm): the same object with a communicator
+    sm.def("ParallelTensorFunctions", [](std::shared_ptr<PyOpf<S>> opf, std::shared_ptr<ParallelCommunicator> comm) {
+        auto t = std::make_shared<PyTf<S>>();
+        t->opf = opf, t->comm = comm;
+        return t;
+    });
+}
+
 PYBIND11_MODULE(b2x_host, m) {
     m.doc() = "C++ host mirror of block2's H.psi interface over the MI355X C ABI (include/b2x.h)";
     py::enum_<DavidsonTypes>(m, "DavidsonTypes", py::arithmetic()) // pybind_core.hpp (same names / values)
@@ -213,10 +303,18 @@ PYBIND11_MODULE(b2x_host, m) {
             s.clear();
             s.keep.clear();
         });
-    py::class_<EffectiveHamiltonian>(m, "EffectiveHamiltonian")
+    py::class_<EffectiveHamiltonian>(m, "EffectiveHamiltonian", py::dynamic_attr())
         .def(py::init([](std::shared_ptr<PySeq> seq, std::vector<double> diag) {
             return new EffectiveHamiltonian(std::static_pointer_cast<BatchGEMMSeq>(seq), diag);
         }))
+        // (the Python object is kept next to the C++ pointer: an override lives in the Python instance)
+        .def_property(
+            "eff_kernel", [](py::object self) -> py::object { return py::getattr(self, "_eff_kernel", py::none()); },
+            [](py::object self, py::object k) {
+                self.cast<EffectiveHamiltonian &>().eff_kernel =
+                    k.is_none() ? nullptr : k.cast<std::shared_ptr<EffectiveKernel>>();
+                py::setattr(self, "_eff_kernel", k);
+            })
         .def("precompute", &EffectiveHamiltonian::precompute)
         .def("post_precompute", &EffectiveHamiltonian::post_precompute)
         .def("__call__",
@@ -289,6 +387,42 @@ PYBIND11_MODULE(b2x_host, m) {
           py::arg("davidson_type") = DavidsonTypes::Normal, py::arg("shift") = 0.0,
           py::arg("ors") = std::vector<uintptr_t>(), py::arg("proj_weights") = std::vector<double>(),
           py::arg("comm") = py::none());
+    // Threading.seq_type + the process-wide instance (pybind_core.hpp:1726-1731, Global.threading)
+    py::class_<Threading, std::shared_ptr<Threading>>(m, "Threading")
+        .def(py::init<>())
+        .def_readwrite("seq_type", &Threading::seq_type);
+    struct GlobalNS {};
+    py::class_<GlobalNS>(m, "Global")
+        .def_property_static(
+            "threading", [](py::object) { return threading_(); },
+            [](py::object, std::shared_ptr<Threading> t) { threading_() = t; });
+    // ParallelCommunicator / the RCCL communicator (pybind_core.hpp:1267-1340: ParallelCommunicator, MPICommunicator);
+    // vectors are DEVICE addresses of fp64 data
+    py::class_<ParallelCommunicator, std::shared_ptr<ParallelCommunicator>>(m, "ParallelCommunicator")
+        .def(py::init<int, int, int>(), py::arg("size") = 1, py::arg("rank") = 0, py::arg("root") = 0)
+        .def_readwrite("size", &ParallelCommunicator::size)
+        .def_readwrite("rank", &ParallelCommunicator::rank)
+        .def_readwrite("root", &ParallelCommunicator::root)
+        .def_readwrite("tcomm", &ParallelCommunicator::tcomm)
+        .def("is_root", &ParallelCommunicator::is_root)
+        .def("allreduce_sum", [](ParallelCommunicator &c, uintptr_t dev, size_t n) { c.allreduce_sum((double *)dev, n); })
+        .def("broadcast", [](ParallelCommunicator &c, uintptr_t dev, size_t n, int owner) { c.broadcast((double *)dev, n, owner); })
+        .def("barrier", &ParallelCommunicator::barrier)
+        .def_property_readonly("handle", [](const ParallelCommunicator &c) { return (uintptr_t)c.handle(); });
+    py::class_<RCCLCommunicator, std::shared_ptr<RCCLCommunicator>, ParallelCommunicator>(m, "RCCLCommunicator")
+        .def(py::init<int, int, const std::string &, int>(), py::arg("rank"), py::arg("size"), py::arg("id_file"),
+             py::arg("root") = 0);
+    py::class_<EffectiveKernel, PyEffectiveKernel, std::shared_ptr<EffectiveKernel>>(m, "EffectiveKernel")
+        .def(py::init<>())
+        .def("compute", [](const EffectiveKernel &k, double beta, py::function f, uintptr_t a, uintptr_t b, std::vector<uintptr_t> xs) {
+            std::vector<const double *> px;
+            for (uintptr_t x : xs)
+                px.push_back((const double *)x);
+            k.EffectiveKernel::compute(beta, [&f](const double *pa, double *pb, double s) { f((uintptr_t)pa, (uintptr_t)pb, s); },
+                                       (const double *)a, (double *)b, px);
+        });
+    bind_functions<SU2>(m, "SU2 instantiation of the hot-path classes");
+    bind_functions<SZ>(m, "SZ instantiation of the hot-path classes");
     b2xh::bind_symbolic(m);
     m.def("device_init", [](int ordinal) { check(b2x_device_init(ordinal)); }, py::arg("ordinal") = 0);
     m.def("small_eigs", [](std::vector<double> a, int n) {
