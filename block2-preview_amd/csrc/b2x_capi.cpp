@@ -10,6 +10,7 @@
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <string>
+#include <mutex>
 #include <vector>
 
 using namespace b2x;
@@ -39,6 +40,69 @@ static hipError_t fill_tail(double *p, uint64_t n) { // n elements: zeros (or Na
     return hipMemset(p, poison() ? 0xFF : 0, n * sizeof(double));
 }
 
+// The big per-plan buffers (W scratch, partial slabs) are recycled between plans: a DMRG sweep creates one plan per site
+// and destroys it before the next, and a hipMalloc of the 16 GiB scratch + 16 GB of slabs of an M=4000 plan costs ~0.7 s
+// (b2x_plan_create 1.05 s against 0.30 s for the plan compiler itself; tools/compile_time.py).  A freed buffer is kept
+// (at most kPoolMax buffers, B2X_POOL_MB MiB in total, default 65536; 0 disables) and handed to the next plan that asks
+// for at most its size and at least half of it.  When an allocation fails the pool is emptied and the allocation retried.
+namespace {
+struct PoolBuf {
+    void *p;
+    size_t bytes;
+};
+std::mutex g_pool_mu;
+std::vector<PoolBuf> g_pool;
+const size_t kPoolMax = 6;
+size_t pool_cap_bytes() {
+    static const size_t cap = (size_t)(getenv("B2X_POOL_MB") ? atoll(getenv("B2X_POOL_MB")) : 65536) << 20;
+    return cap;
+}
+void pool_trim_locked(size_t keep_bytes) {
+    size_t tot = 0;
+    for (const PoolBuf &b : g_pool)
+        tot += b.bytes;
+    while (!g_pool.empty() && (tot > keep_bytes || g_pool.size() > kPoolMax)) { // oldest first
+        tot -= g_pool.front().bytes;
+        (void)hipFree(g_pool.front().p);
+        g_pool.erase(g_pool.begin());
+    }
+}
+hipError_t pool_alloc(void **out, size_t bytes, size_t *got) {
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        int best = -1;
+        for (size_t i = 0; i < g_pool.size(); i++)
+            if (g_pool[i].bytes >= bytes && g_pool[i].bytes / 2 <= bytes && (best < 0 || g_pool[i].bytes < g_pool[best].bytes))
+                best = (int)i;
+        if (best >= 0) {
+            *out = g_pool[best].p, *got = g_pool[best].bytes;
+            g_pool.erase(g_pool.begin() + best);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        pool_trim_locked(0);
+        e = hipMalloc(out, bytes);
+    }
+    *got = bytes;
+    return e;
+}
+void pool_free(void *p, size_t bytes) {
+    if (!p)
+        return;
+    if (pool_cap_bytes() == 0 || bytes < ((size_t)64 << 20) || bytes > pool_cap_bytes()) { // small buffers: not worth keeping
+        (void)hipFree(p);
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool.push_back(PoolBuf{p, bytes});
+    pool_trim_locked(pool_cap_bytes());
+}
+} // namespace
+
 struct b2x_arena {
     double *dev = nullptr;
     uint64_t len = 0;
@@ -66,6 +130,7 @@ struct b2x_plan {
     GItem *d_gitems = nullptr;
     DTile *d_gtiles = nullptr;
     double *d_scratch = nullptr, *d_gslabs = nullptr;
+    size_t scratch_bytes = 0, gslabs_bytes = 0, slabs_bytes = 0; // (pool_alloc / pool_free)
     OWork *d_sum_work = nullptr;   // sum pass between the stages (distributive law), scratch -> scratch
     OEntry *d_sum_entries = nullptr;
     std::vector<SuperStep> steps;
@@ -98,6 +163,9 @@ struct b2x_plan {
 };
 
 static void plan_free(b2x_plan *p) {
+    // (hipFree waits for the device; buffers that go back to the pool must be idle as well before another plan gets them)
+    if (p->d_scratch || p->d_gslabs || p->d_slabs)
+        (void)hipDeviceSynchronize();
     for (int k = 0; k < kNumClasses; k++) {
         if (p->d_parts[k])
             (void)hipFree(p->d_parts[k]);
@@ -106,8 +174,7 @@ static void plan_free(b2x_plan *p) {
     }
     if (p->d_tiles)
         (void)hipFree(p->d_tiles);
-    if (p->d_slabs)
-        (void)hipFree(p->d_slabs);
+    pool_free(p->d_slabs, p->slabs_bytes);
     if (p->d_pairs)
         (void)hipFree(p->d_pairs);
     if (p->d_gsegs)
@@ -116,14 +183,12 @@ static void plan_free(b2x_plan *p) {
         (void)hipFree(p->d_gitems);
     if (p->d_gtiles)
         (void)hipFree(p->d_gtiles);
-    if (p->d_scratch)
-        (void)hipFree(p->d_scratch);
+    pool_free(p->d_scratch, p->scratch_bytes);
     if (p->d_sum_work)
         (void)hipFree(p->d_sum_work);
     if (p->d_sum_entries)
         (void)hipFree(p->d_sum_entries);
-    if (p->d_gslabs)
-        (void)hipFree(p->d_gslabs);
+    pool_free(p->d_gslabs, p->gslabs_bytes);
     if (p->d_psi)
         (void)hipFree(p->d_psi);
     if (p->d_sigma)
@@ -188,7 +253,7 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
             rc = upload(&p->d_sum_entries, cp.sum_entries);
         p->steps = cp.steps;
         if (rc == B2X_OK && cp.scratch_elems) {
-            hipError_t e = hipMalloc((void **)&p->d_scratch, (cp.scratch_elems + kSlackElems) * sizeof(double));
+            hipError_t e = pool_alloc((void **)&p->d_scratch, (cp.scratch_elems + kSlackElems) * sizeof(double), &p->scratch_bytes);
             if (e != hipSuccess)
                 rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(W scratch): ") + hipGetErrorString(e));
             // the scratch only ever holds finite values: zeroed here, written by the kernels with products of the inputs
@@ -233,12 +298,12 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
                 (void)hipFree(de);
         }
         if (rc == B2X_OK && cp.gslab_elems) {
-            hipError_t e = hipMalloc((void **)&p->d_gslabs, cp.gslab_elems * sizeof(double));
+            hipError_t e = pool_alloc((void **)&p->d_gslabs, cp.gslab_elems * sizeof(double), &p->gslabs_bytes);
             if (e != hipSuccess)
                 rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
         }
         if (rc == B2X_OK && cp.slab_elems) {
-            hipError_t e = hipMalloc((void **)&p->d_slabs, cp.slab_elems * sizeof(double));
+            hipError_t e = pool_alloc((void **)&p->d_slabs, cp.slab_elems * sizeof(double), &p->slabs_bytes);
             if (e != hipSuccess)
                 rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
         }
