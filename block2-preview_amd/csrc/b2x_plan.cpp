@@ -916,6 +916,12 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 key[4] = ((uint64_t)p.n0 << 32) | (uint32_t)p.lda0, key[5] = ((uint64_t)p.ldb0 << 8) | p.tb0, key[6] = 0;
         };
         std::vector<Cand> cand;
+        {
+            size_t nc = 0;
+            for (const Component *c : big)
+                nc += c->w_end - c->w_begin;
+            cand.reserve(nc);
+        }
         for (const Component *c : big)
             for (uint32_t wi = c->w_begin; wi < c->w_end; wi++) {
                 Cand cd{};
@@ -924,29 +930,32 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             }
         if (allow_flip) {
             // order of each pair: stage-0 cost amortised over the pairs that would share the product + its own stage 1
-            struct KeyRef {
-                uint64_t key[7];
-                uint32_t idx;
-            };
-            auto group_sizes = [&](bool fl) {
-                std::vector<KeyRef> ks(cand.size());
-                for (size_t q = 0; q < cand.size(); q++)
-                    make_key(ep[win[cand[q].wi].pair], fl, ks[q].key), ks[q].idx = (uint32_t)q;
-                std::sort(ks.begin(), ks.end(), [](const KeyRef &x, const KeyRef &y) {
+            auto group_sizes = [&](bool fl) { // size of every candidate's sharing group: hash table on the 7-word key
+                struct Slot {
+                    uint64_t key[7];
+                    uint32_t count, used;
+                };
+                size_t cap = 64;
+                while (cap < 2 * cand.size())
+                    cap <<= 1;
+                std::vector<Slot> tab(cap);
+                std::vector<uint32_t> slot_of(cand.size());
+                for (size_t q = 0; q < cand.size(); q++) {
+                    uint64_t key[7];
+                    make_key(ep[win[cand[q].wi].pair], fl, key);
+                    uint64_t h = 0x9E3779B97F4A7C15ull;
                     for (int k = 0; k < 7; k++)
-                        if (x.key[k] != y.key[k])
-                            return x.key[k] < y.key[k];
-                    return false;
-                });
-                std::vector<uint32_t> sz(cand.size(), 1);
-                for (size_t a = 0; a < ks.size();) {
-                    size_t b = a + 1;
-                    while (b < ks.size() && std::equal(ks[a].key, ks[a].key + 7, ks[b].key))
-                        b++;
-                    for (size_t q = a; q < b; q++)
-                        sz[ks[q].idx] = (uint32_t)(b - a);
-                    a = b;
+                        h = (h ^ key[k]) * 0xBF58476D1CE4E5B9ull, h ^= h >> 29;
+                    size_t i = (size_t)h & (cap - 1);
+                    while (tab[i].used && !std::equal(key, key + 7, tab[i].key))
+                        i = (i + 1) & (cap - 1);
+                    if (!tab[i].used)
+                        tab[i].used = 1, std::copy(key, key + 7, tab[i].key);
+                    tab[i].count++, slot_of[q] = (uint32_t)i;
                 }
+                std::vector<uint32_t> sz(cand.size());
+                for (size_t q = 0; q < cand.size(); q++)
+                    sz[q] = tab[slot_of[q]].count;
                 return sz;
             };
             const std::vector<uint32_t> g0 = group_sizes(false), g1 = group_sizes(true);
