@@ -886,7 +886,8 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
 // each class is one launch of the instantiation that serves it
 // which: 0 = both classes on `st`, 1 = the tall class only, 2 = the short class only
 hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_begin, const double *arena,
-                     const double *psi, double *scratch, double *slabs, bool seg_scaled, int tile_n, hipStream_t st, int which) {
+                     const double *psi, double *scratch, double *slabs, bool seg_scaled, int tile_n, hipStream_t st, int which,
+                     bool short_narrow) {
     // chunk depth 16: a 32-deep chunk halves the barriers (+2 % on uniform 1024^3 pairs) but pads every K to 32 and
     // spills at 256 VGPRs (-2 % on the M=4000 plan)
 #define B2X_GG_LAUNCH(NWV, SBV, TMAXV, B, E)                                                                           \
@@ -894,7 +895,14 @@ hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_beg
     hipLaunchKernelGGL((gg_kernel<kGGCF, NWV, 16, SBV, TMAXV>), dim3((E) - (B)), dim3(NWV * 64), 0, st, segs, items + (B), \
                        arena, psi, scratch, slabs)
     const int nw = tile_n / (16 * kGGCF); // waves per workgroup: 4 (128-column tiles) or 2 (narrow sectors)
-    const uint32_t b0 = which == 2 ? v_begin[1] : v_begin[0], b1 = v_begin[1], b2 = which == 1 ? v_begin[1] : v_begin[kGGVariants];
+    const uint32_t b0 = which == 2 ? v_begin[1] : v_begin[0], b1 = v_begin[1];
+    uint32_t b2 = which == 1 ? v_begin[1] : v_begin[kGGVariants];
+    if (short_narrow && b2 > b1) { // the short class as 1-wave workgroups of 32 columns (H.psi plans: the SCALED variant)
+        if (!seg_scaled)
+            return hipErrorInvalidValue;
+        B2X_GG_LAUNCH(1, true, kGGNarrowFrags, b1, b2);
+        b2 = b1;
+    }
     if (nw >= 4) {
         if (seg_scaled) {
             B2X_GG_LAUNCH(4, true, 8, b0, b1);

@@ -55,8 +55,8 @@ std::vector<int> wave_cuts(int total, int tile) {
 // Row cuts for the grouped-GEMM kernel, which has a body for every tile height that is a multiple of 16 rows
 // (<= 256): split `total` into ceil(U/16) pieces of near-equal size in units of 16 (U = ceil(total/16)), so the
 // issued rows are 16*U (the minimum) and no piece is needlessly small.
-std::vector<int> unit_cuts(int total) {
-    const int U = ceil_div(total, kGGRowUnit), n = ceil_div(U, kGGTileM / kGGRowUnit);
+std::vector<int> unit_cuts(int total, int max_units = kGGTileM / kGGRowUnit) {
+    const int U = ceil_div(total, kGGRowUnit), n = ceil_div(U, max_units);
     std::vector<int> cuts{0};
     int pos = 0;
     for (int i = 0; i < n; i++) {
@@ -425,6 +425,23 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             }
         const int TN = (wsum > 0 && wn / wsum < 300.0) ? 64 : kGGTileN;
         out.gg_tile_n = TN;
+        // Short tiles of plans with narrow sectors run on ONE-WAVE workgroups of 32 columns (gg_kernel<CF, NW = 1, ...,
+        // TMAX = kGGNarrowFrags>: 116 VGPRs, 8 KB of LDS, 16 independent workgroups per CU): in a 2-wave workgroup the
+        // second wave of a tile of <= 32 columns only helps staging A (at M=250 that is 59 % of the stage-0 chunks), yet
+        // holds a wave slot.  Row ranges of up to 48 rows are cut into tiles of at most kGGNarrowFrags fragments, and the
+        // columns of such a row tile at 32 instead of TN.  B2X_NARROW=0 keeps the 2-wave short-tile instantiation.
+        static const int narrow_env = getenv("B2X_NARROW") ? atoi(getenv("B2X_NARROW")) : 1;
+        // Only where segments are short as well (MAC-weighted mean output width < 90: the M=250 class; measured on one box:
+        // Cr2 M=250 kernel time -11 %, M=500 +22 %, M=1000 +3 %, uniform-M Cr2 M=1000 +17 % — with longer K the two waves
+        // of a 64-column tile share the A staging to better effect than two 1-wave workgroups that stage it twice).
+        static const double narrow_w = getenv("B2X_NARROW_W") ? atof(getenv("B2X_NARROW_W")) : 90.0;
+        const bool use_narrow = narrow_env != 0 && TN == 64 && wsum > 0 && wn / wsum < narrow_w;
+        out.short_narrow = use_narrow;
+        const int short_rows = (use_narrow ? kGGNarrowFrags : kGGShortFrags) * kGGRowUnit;
+        auto row_cuts = [&](int total) {
+            return use_narrow && total <= kGGShortFrags * kGGRowUnit ? unit_cuts(total, kGGNarrowFrags) : unit_cuts(total);
+        };
+        auto col_tile = [&](int rows) { return use_narrow && rows <= short_rows ? kGGNarrowN : TN; };
         // effective pairs of this path: an operator pre-sum (below) replaces the second operator of a merged pair by a
         // block in the plan's own buffer (source 2 = scratch, whose first aux_len elements persist across executions)
         std::vector<b2x_pair> ep(pairs, pairs + n_pairs);
@@ -487,9 +504,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 if (!pw.owner)
                     continue;
                 if (pw.flip) { // W'(m1 x k0) = op(Z)(m1 x k1) . X(k1 x k0)
-                    std::vector<int> rc = unit_cuts(p.m1), cc = wave_cuts(p.k0, TN);
+                    std::vector<int> rc = row_cuts(p.m1);
                     const BGroup bg = s0_group(((uint64_t)1 << 63) | p.x_off, rc.size() - 1);
-                    for (size_t a = 0; a + 1 < rc.size(); a++)
+                    for (size_t a = 0; a + 1 < rc.size(); a++) {
+                        const std::vector<int> cc = wave_cuts(p.k0, col_tile(rc[a + 1] - rc[a]));
                         for (size_t b = 0; b + 1 < cc.size(); b++) {
                             s0_push_key(bg, a, b);
                             GSeg g{};
@@ -509,11 +527,13 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             out.gitems.push_back(it);
                             gg_macs += (uint64_t)g.mr * g.nc * g.K;
                         }
+                    }
                     continue;
                 }
-                std::vector<int> rc = unit_cuts(p.k1), cc = wave_cuts(p.n0, TN);
+                std::vector<int> rc = row_cuts(p.k1);
                 const BGroup bg = s0_group(((uint64_t)ysrc[win[pw.wi].pair] << 62) | p.y_off, rc.size() - 1);
-                for (size_t a = 0; a + 1 < rc.size(); a++)
+                for (size_t a = 0; a + 1 < rc.size(); a++) {
+                    const std::vector<int> cc = wave_cuts(p.n0, col_tile(rc[a + 1] - rc[a]));
                     for (size_t b = 0; b + 1 < cc.size(); b++) {
                         s0_push_key(bg, a, b);
                         GSeg g{};
@@ -533,6 +553,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         out.gitems.push_back(it);
                         gg_macs += (uint64_t)g.mr * g.nc * g.K;
                     }
+                }
             }
             const uint32_t s1_begin = (uint32_t)out.gitems.size();
             std::vector<uint32_t> tile_of_item; // stage-1 items in creation order -> running number of their tile
@@ -562,15 +583,24 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
                 std::vector<int> rc;
                 for (size_t bi = 0; bi + 1 < bounds.size(); bi++) {
-                    std::vector<int> sub = unit_cuts(bounds[bi + 1] - bounds[bi]);
+                    std::vector<int> sub = row_cuts(bounds[bi + 1] - bounds[bi]);
                     for (size_t k = 0; k + 1 < sub.size(); k++)
                         rc.push_back(bounds[bi] + sub[k]);
                 }
                 rc.push_back(c.rows);
-                std::vector<int> cc = wave_cuts(c.cols, TN);
-                int nrt = (int)rc.size() - 1, nct = (int)cc.size() - 1;
-                std::vector<std::vector<GSeg>> tsegs((size_t)nrt * nct);
-                std::vector<double> tcost((size_t)nrt * nct, 0.0);
+                // column cuts per ROW TILE: short row tiles (1-wave workgroups) are cut at 32 columns, the others at TN
+                const std::vector<int> cc_wide = wave_cuts(c.cols, TN), cc_narrow = wave_cuts(c.cols, kGGNarrowN);
+                int nrt = (int)rc.size() - 1;
+                std::vector<const std::vector<int> *> ccs(nrt);
+                std::vector<size_t> tbase(nrt + 1, 0);
+                int nct_max = 1;
+                for (int a = 0; a < nrt; a++) {
+                    ccs[a] = col_tile(rc[a + 1] - rc[a]) == TN ? &cc_wide : &cc_narrow;
+                    tbase[a + 1] = tbase[a] + (ccs[a]->size() - 1);
+                    nct_max = std::max(nct_max, (int)ccs[a]->size() - 1);
+                }
+                std::vector<std::vector<GSeg>> tsegs(tbase[nrt]);
+                std::vector<double> tcost(tbase[nrt], 0.0);
                 // Distributive law: pairs of this sector that multiply the SAME operator block into the SAME window
                 // (op(Z) . W_i with one Z, or W'_i . op(Y) with one Y) first sum their scaled stage-0 products,
                 // S = sum_i alpha_i W_i, in an element-wise pass between the stages, then take ONE stage-1 product.
@@ -647,8 +677,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     uint64_t rel = w.off - c.base;
                     int row0 = (int)(rel / (uint64_t)c.ld), col0 = (int)(rel % (uint64_t)c.ld);
                     int a0 = (int)(std::upper_bound(rc.begin(), rc.end(), row0) - rc.begin()) - 1;
-                    int b0 = (int)(std::upper_bound(cc.begin(), cc.end(), col0) - cc.begin()) - 1;
-                    for (int a = a0; a < nrt && rc[a] < row0 + w.m; a++)
+                    for (int a = a0; a < nrt && rc[a] < row0 + w.m; a++) {
+                        const std::vector<int> &cc = *ccs[a];
+                        const int nct = (int)cc.size() - 1;
+                        int b0 = (int)(std::upper_bound(cc.begin(), cc.end(), col0) - cc.begin()) - 1;
                         for (int b = b0; b < nct && cc[b] < col0 + w.n; b++) {
                             int ra = std::max(row0, rc[a]), rb = std::min(row0 + w.m, rc[a + 1]);
                             int ca = std::max(col0, cc[b]), cb = std::min(col0 + w.n, cc[b + 1]);
@@ -673,15 +705,18 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             }
                             g.mr = rb - ra, g.nc = cb - ca;
                             g.tc0 = ca - cc[b]; // (ra == rc[a]: rows are cut at every window boundary)
-                            size_t t = (size_t)a * nct + b;
+                            size_t t = tbase[a] + b;
                             tsegs[t].push_back(g);
                             tcost[t] += (double)round_up(g.mr, 16) * round_up(g.nc, 16) * round_up(g.K, 16) + 65536.0;
                             gg_macs += (uint64_t)g.mr * g.nc * g.K;
                         }
+                    }
                 }
-                for (int a = 0; a < nrt; a++)
+                for (int a = 0; a < nrt; a++) {
+                    const std::vector<int> &cc = *ccs[a];
+                    const int nct = (int)cc.size() - 1;
                     for (int b = 0; b < nct; b++) {
-                        size_t t = (size_t)a * nct + b;
+                        size_t t = tbase[a] + b;
                         if (tsegs[t].empty())
                             continue;
                         DTile dt{};
@@ -715,12 +750,13 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         out.gtiles.push_back(dt);
                         // sibling order: 4 x 4 blocks of tiles (a tile shares its A operands with the tiles of its row and
                         // its B operands with those of its column: a square block shares both)
-                        const uint32_t blk = (uint32_t)((a / 4) * ceil_div(nct, 4) + b / 4);
+                        const uint32_t blk = (uint32_t)((a / 4) * ceil_div(nct_max, 4) + b / 4);
                         const uint32_t key = (tile_sector << 20) | (blk << 4) | (uint32_t)((a % 4) * 4 + b % 4);
                         for (int m2 = 0; m2 < made; m2++)
                             tile_of_item[tile_of_item.size() - 1 - m2] = key;
                         tile_seq++;
                     }
+                }
                 tile_sector++;
                 i = j;
             }
@@ -746,14 +782,16 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 for (uint32_t ii = b; ii < e; ii++) {
                     const double c = (double)icost(out.gitems[ii]);
                     tot += c;
-                    if (out.gitems[ii].rows <= kGGShortFrags * kGGRowUnit)
+                    if (out.gitems[ii].rows <= short_rows)
                         sh += c;
                 }
                 return tot > 0 ? sh / tot : 0.0;
             };
             static const double thr = getenv("B2X_SPLIT_THR") ? atof(getenv("B2X_SPLIT_THR")) : 0.3;
-            const bool split0 = short_share(s0_begin, s1_begin) >= thr, split1 = short_share(s1_begin, s1_end) >= thr;
-            auto tall = [](const GItem &x) { return x.rows > kGGShortFrags * kGGRowUnit; };
+            // (the 1-wave workgroups are a launch of their own whenever a stage has short tiles at all)
+            const double thr_eff = use_narrow ? 1e-30 : thr;
+            const bool split0 = short_share(s0_begin, s1_begin) >= thr_eff, split1 = short_share(s1_begin, s1_end) >= thr_eff;
+            auto tall = [short_rows](const GItem &x) { return x.rows > short_rows; };
             // Stage 0: one workgroup per W tile.  Workgroup ids i, i + 8, i + 16, ... run on one XCD (one L2, whose lines
             // live a few microseconds under this traffic): the items of a locality group (s0_key) are handed to ONE XCD as
             // consecutive workgroups, so that all but the first find their B tile / A rows in that L2.  Groups go

@@ -55,6 +55,23 @@ int b2x_debug_compile_and_emulate(size_t n_pairs, const b2x_pair *pairs, size_t 
         *stats = cp.stats;
     if (fallback)
         *fallback = cp.fallback ? 1 : 0;
+    // launch contract of the 1-wave workgroups: their class holds only tiles of <= kGGNarrowFrags fragments x kGGNarrowN columns
+    if (cp.short_narrow)
+        for (const SuperStep &ss : cp.steps)
+            for (int stg = 0; stg < 2; stg++) {
+                const uint32_t *v = stg ? ss.s1_v : ss.s0_v;
+                for (uint32_t i = v[1]; i < v[kGGVariants]; i++) {
+                    const GItem &it = cp.gitems[i];
+                    bool ok = it.rows >= 1 && it.rows <= kGGNarrowFrags * kGGRowUnit && it.cols >= 1 && it.cols <= kGGNarrowN;
+                    for (uint32_t sg = it.seg_begin; sg < it.seg_end && ok; sg++)
+                        ok = cp.gsegs[sg].mr == it.rows && cp.gsegs[sg].tc0 >= 0 && cp.gsegs[sg].tc0 + cp.gsegs[sg].nc <= it.cols;
+                    if (!ok)
+                        return fail(B2X_ERR_INVALID, "narrow-class item outside the 1-wave kernel's contract");
+                }
+                for (uint32_t i = v[0]; i < v[1]; i++)
+                    if (cp.gitems[i].rows <= kGGNarrowFrags * kGGRowUnit)
+                        return fail(B2X_ERR_INVALID, "short tile in the tall class of a narrow plan");
+            }
     if (!cp.fallback && arena && psi && sigma)
         emulate_plan_host(cp, arena, psi, sigma, scale);
     if (getenv("B2X_TEST_TRAFFIC_MODEL")) { // operand bytes the grouped-GEMM work list requests, per stage and source
