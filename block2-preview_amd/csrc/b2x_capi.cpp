@@ -143,6 +143,7 @@ struct b2x_plan {
     int dominant_cls = 0;
     bool seg_scaled = false; // single-GEMM list plan (gg_kernel SCALED variant)
     bool short_narrow = false; // the short tile class runs as 1-wave workgroups
+    int short_frags = kGGShortFrags;
     int gg_tile_n = 128;
     // The launches of one H.psi as a HIP graph (device-pointer execute only): captured on first use, replayed with the
     // psi / sigma / scale arguments of its kernel nodes patched per call.  An H.psi of a small plan is a handful of
@@ -228,6 +229,7 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
     p->n_pairs = (uint32_t)n_pairs;
     p->seg_scaled = cp.seg_scaled;
     p->short_narrow = cp.short_narrow;
+    p->short_frags = cp.short_frags;
     p->gg_tile_n = cp.gg_tile_n;
     if (p->fallback) {
         std::vector<b2x_pair> pv(pairs, pairs + n_pairs);
@@ -488,7 +490,7 @@ int b2x_gemm_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_gemms,
 static int launch_stage(b2x_plan *p, const uint32_t *v, const double *psi, hipStream_t st) {
     const bool both = v[1] > v[0] && v[kGGVariants] > v[1];
     if (!both) {
-        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st, 0, p->short_narrow));
+        HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st, 0, p->short_narrow, p->short_frags));
         return B2X_OK;
     }
     if (!p->aux_stream) {
@@ -498,9 +500,9 @@ static int launch_stage(b2x_plan *p, const uint32_t *v, const double *psi, hipSt
     }
     HIPCHK(hipEventRecord(p->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(p->aux_stream, p->ev_fork, 0));
-    HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, p->aux_stream, 2, p->short_narrow));
+    HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, p->aux_stream, 2, p->short_narrow, p->short_frags));
     HIPCHK(hipEventRecord(p->ev_join, p->aux_stream));
-    HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st, 1, p->short_narrow));
+    HIPCHK(launch_gg(p->d_gsegs, p->d_gitems, v, p->arena->dev, psi, p->d_scratch, p->d_gslabs, p->seg_scaled, p->gg_tile_n, st, 1, p->short_narrow, p->short_frags));
     HIPCHK(hipStreamWaitEvent(st, p->ev_join, 0));
     return B2X_OK;
 }

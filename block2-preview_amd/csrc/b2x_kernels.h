@@ -9,7 +9,7 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
                        const double *psi, double *slabs, hipStream_t st);
 hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_begin, const double *arena,
                      const double *psi, double *scratch, double *slabs, bool seg_scaled, int tile_n, hipStream_t st, int which = 0,
-                     bool short_narrow = false);
+                     bool short_narrow = false, int short_frags = kGGShortFrags);
 hipError_t launch_outer(const OWork *work, uint32_t n_work, const OEntry *entries, const double *arena, const double *in,
                         double *out, int rows_in_flight, hipStream_t st);
 hipError_t launch_reduce(const DTile *tiles, uint32_t n_tiles, const double *slabs, double *sigma, double scale,

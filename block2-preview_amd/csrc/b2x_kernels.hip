@@ -574,12 +574,13 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
 // partners independent barriers, and wastes less on the many sectors shorter than 256 rows:
 // M=1000 26.2 -> 29.6, M=4000 52.3 -> 55.2 TFLOP/s on the bench plan, 62.3 on uniform 1024^3 pairs.
 // TMAX = tallest tile (in 16-row fragments) this instantiation serves.  The register count of a kernel is that of its
-// tallest body, so the short tiles (<= 16 kGGShortFrags = 48 rows: the sectors of small bond dimensions, where a segment
+// tallest body, so the short tiles (<= 16 kGGShortFrags = 48 rows, or <= 80 rows at 3 waves per SIMD for plans of mid-height
+// sectors: CompiledPlan::short_frags; the sectors of small bond dimensions, where a segment
 // is one or two chunks long and the exposed load latency, not the MFMA pipe, sets the pace) get an instantiation of
 // their own with half the registers (<= 128: no spills up to three row fragments) and 3/8 of the LDS: four waves per
 // SIMD instead of two hide that latency.
 template <int CF, int NW, int KC, bool SB, int TMAX>
-__global__ __launch_bounds__(NW * 64, TMAX <= kGGShortFrags ? 4 : 2) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
+__global__ __launch_bounds__(NW * 64, TMAX <= 3 ? 4 : (TMAX <= 5 ? 3 : 2)) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
                                                          const double *__restrict__ arena,
                                                          const double *__restrict__ psi, double *__restrict__ scratch,
                                                          double *__restrict__ slabs) {
@@ -887,7 +888,7 @@ hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t
 // which: 0 = both classes on `st`, 1 = the tall class only, 2 = the short class only
 hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_begin, const double *arena,
                      const double *psi, double *scratch, double *slabs, bool seg_scaled, int tile_n, hipStream_t st, int which,
-                     bool short_narrow) {
+                     bool short_narrow, int short_frags) {
     // chunk depth 16: a 32-deep chunk halves the barriers (+2 % on uniform 1024^3 pairs) but pads every K to 32 and
     // spills at 256 VGPRs (-2 % on the M=4000 plan)
 #define B2X_GG_LAUNCH(NWV, SBV, TMAXV, B, E)                                                                           \
@@ -901,6 +902,14 @@ hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_beg
         if (!seg_scaled)
             return hipErrorInvalidValue;
         B2X_GG_LAUNCH(1, true, kGGNarrowFrags, b1, b2);
+        b2 = b1;
+    }
+    if (seg_scaled && short_frags == kGGMidFrags && b2 > b1) { // short class of up to 5 row fragments (3 waves / SIMD)
+        if (nw >= 4) {
+            B2X_GG_LAUNCH(4, true, kGGMidFrags, b1, b2);
+        } else {
+            B2X_GG_LAUNCH(2, true, kGGMidFrags, b1, b2);
+        }
         b2 = b1;
     }
     if (nw >= 4) {

@@ -425,6 +425,36 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             }
         const int TN = (wsum > 0 && wn / wsum < 300.0) ? 64 : kGGTileN;
         out.gg_tile_n = TN;
+        // Height of the short tile class.  Its kernel instantiation serves tiles of up to 3 row fragments with <= 128 VGPRs
+        // (4 waves per SIMD), or of up to 5 with <= 168 (3 waves per SIMD; the tall instantiation: 2).  Plans whose work
+        // sits in 4-5-fragment tiles (the M=1000-2000 class: 66 % / 44 % of the MFMA issue slots of the Cr2 plan) take the
+        // second (M=1000 -3 %, M=2000 -2 % on one box), plans with a real share of <= 3-fragment tiles keep the first
+        // (uniform-M Cr2 M=1000: +3 % with 5).  Shares estimated from the pairs' row counts, MAC-weighted.
+        {
+            double w3 = 0, w5 = 0, wt = 0;
+            for (const Component *c : big)
+                for (uint32_t wi = c->w_begin; wi < c->w_end; wi++) {
+                    const b2x_pair &p = pairs[win[wi].pair];
+                    const double w = (double)p.m0 * p.n0 * p.k0 + (double)p.m1 * p.n1 * p.k1;
+                    for (int rows : {p.m1, p.k1}) {
+                        const std::vector<int> rc = unit_cuts(rows);
+                        for (size_t a = 0; a + 1 < rc.size(); a++) {
+                            const int fr = ceil_div(rc[a + 1] - rc[a], kGGRowUnit);
+                            const double ws = 0.5 * w * (rc[a + 1] - rc[a]) / rows;
+                            wt += ws;
+                            if (fr <= kGGShortFrags)
+                                w3 += ws;
+                            else if (fr <= kGGMidFrags)
+                                w5 += ws;
+                        }
+                    }
+                }
+            static const int sf_env = getenv("B2X_SHORT_FRAGS") ? atoi(getenv("B2X_SHORT_FRAGS")) : 0;
+            out.short_frags = sf_env == kGGShortFrags || sf_env == kGGMidFrags
+                                  ? sf_env
+                                  : (wt > 0 && w3 / wt < 0.25 && w5 / wt > 0.3 ? kGGMidFrags : kGGShortFrags);
+        }
+        const int short_frags = out.short_frags;
         // Short tiles of plans with narrow sectors run on ONE-WAVE workgroups of 32 columns (gg_kernel<CF, NW = 1, ...,
         // TMAX = kGGNarrowFrags>: 116 VGPRs, 8 KB of LDS, 16 independent workgroups per CU): in a 2-wave workgroup the
         // second wave of a tile of <= 32 columns only helps staging A (at M=250 that is 59 % of the stage-0 chunks), yet
@@ -437,7 +467,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         static const double narrow_w = getenv("B2X_NARROW_W") ? atof(getenv("B2X_NARROW_W")) : 90.0;
         const bool use_narrow = narrow_env != 0 && TN == 64 && wsum > 0 && wn / wsum < narrow_w;
         out.short_narrow = use_narrow;
-        const int short_rows = (use_narrow ? kGGNarrowFrags : kGGShortFrags) * kGGRowUnit;
+        const int short_rows = (use_narrow ? kGGNarrowFrags : short_frags) * kGGRowUnit;
         auto row_cuts = [&](int total) {
             return use_narrow && total <= kGGShortFrags * kGGRowUnit ? unit_cuts(total, kGGNarrowFrags) : unit_cuts(total);
         };

@@ -124,7 +124,8 @@ static const int kGGTileM = 128, kGGTileN = 128;
 static const int kGGCF = 2;
 static const int kGGRowUnit = 16; // tile heights are multiples of one MFMA row fragment
 static const int kGGNarrowFrags = 2, kGGNarrowN = 32; // 1-wave workgroups: tiles of up to kGGNarrowFrags row fragments x kGGNarrowN columns
-static const int kGGShortFrags = 3; // tiles of up to this many row fragments run on the low-register kernel instantiation
+static const int kGGShortFrags = 3, kGGMidFrags = 5; // the short class holds tiles of up to 3 row fragments (4 waves/SIMD) or, for plans of
+                                                      // mid-height sectors, up to 5 (3 waves/SIMD): CompiledPlan::short_frags // tiles of up to this many row fragments run on the low-register kernel instantiation
 
 // kernel classes of the fused path.  nw = tile width / 16, tmf = tile height / 16, k1f = k1 chunk / 16.
 // All fused classes run hpsi_wave — one WAVE per work item, operands straight from L2 into MFMA fragments, no LDS,
@@ -156,6 +157,7 @@ struct CompiledPlan {
     uint64_t scratch_elems = 0, gslab_elems = 0;
     bool fallback = false; // windows could not be segmented -> generic atomic kernel
     std::string fallback_reason;
+    int short_frags = kGGShortFrags; // tallest tile (row fragments) of the short class of this plan: kGGShortFrags or kGGMidFrags
     bool short_narrow = false; // the short tile class ([v[1], v[last]) of every stage) holds tiles of <= 32 x 32: 1-wave workgroups
     bool seg_scaled = false; // single-GEMM list: segments carry their own alpha (gg_kernel SCALED variant)
     int gg_tile_n = kGGTileN; // column width of the grouped-GEMM tiles of this plan: 128 (4 waves) or 64 (2 waves)

@@ -110,6 +110,28 @@ int b2x_debug_compile_and_emulate(size_t n_pairs, const b2x_pair *pairs, size_t 
                     (unsigned long long)n32, (unsigned long long)c32, (unsigned long long)call, (unsigned long long)n64,
                     (unsigned long long)nw);
         }
+        {
+            double byf[2][17] = {};
+            for (const SuperStep &ss : cp.steps)
+                for (int stg = 0; stg < 2; stg++) {
+                    const uint32_t *v = stg ? ss.s1_v : ss.s0_v;
+                    for (uint32_t i = v[0]; i < v[kGGVariants]; i++) {
+                        const GItem &it = cp.gitems[i];
+                        const int fr = (it.rows + 15) / 16;
+                        for (uint32_t sg = it.seg_begin; sg < it.seg_end; sg++)
+                            byf[stg][std::min(fr, 16)] += (double)fr * ((cp.gsegs[sg].K + 15) / 16);
+                    }
+                }
+            for (int stg = 0; stg < 2; stg++) {
+                double tot = 0;
+                for (int f = 1; f <= 16; f++)
+                    tot += byf[stg][f];
+                fprintf(stderr, "stage %d issue-slot share by row fragments:", stg);
+                for (int f = 1; f <= 8; f++)
+                    fprintf(stderr, " %d:%.3f", f, tot > 0 ? byf[stg][f] / tot : 0.0);
+                fprintf(stderr, "\n");
+            }
+        }
         for (int stg = 0; stg < 2; stg++)
             fprintf(stderr, "stage %d: items %llu segs %llu chunks %llu | A arena %.3f psi %.3f scratch %.3f | B arena %.3f psi %.3f "
                     "scratch %.3f | out %.3f GB\n", stg, (unsigned long long)nit[stg], (unsigned long long)nseg[stg],
