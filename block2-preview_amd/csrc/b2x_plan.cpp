@@ -468,8 +468,9 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         const bool use_narrow = narrow_env != 0 && TN == 64 && wsum > 0 && wn / wsum < narrow_w;
         out.short_narrow = use_narrow;
         const int short_rows = (use_narrow ? kGGNarrowFrags : short_frags) * kGGRowUnit;
+        static const int max_units_env = getenv("B2X_MAX_UNITS") ? atoi(getenv("B2X_MAX_UNITS")) : kGGTileM / kGGRowUnit; // (probe)
         auto row_cuts = [&](int total) {
-            return use_narrow && total <= kGGShortFrags * kGGRowUnit ? unit_cuts(total, kGGNarrowFrags) : unit_cuts(total);
+            return use_narrow && total <= kGGShortFrags * kGGRowUnit ? unit_cuts(total, kGGNarrowFrags) : unit_cuts(total, max_units_env);
         };
         auto col_tile = [&](int rows) { return use_narrow && rows <= short_rows ? kGGNarrowN : TN; };
         // effective pairs of this path: an operator pre-sum (below) replaces the second operator of a merged pair by a
