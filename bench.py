@@ -206,6 +206,10 @@ def site_step(scale, M, hpsi_ms, compile_s, dev, log):
     out["noise_compile_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     out["noise_ms"] = round(timed(lambda: plan.execute_device(vin.data_ptr(), vout.data_ptr(), 1.0, stream)), 3)
     out["noise_operator_gb"] = round(gl.arena_len * 8 / 1e9, 2)
+    plan.close()
+    t0 = time.perf_counter()
+    plan = capi.GemmPlan(arena, gl.gemms, gl.in_len, gl.out_len)  # the same list again: from the compiled-plan cache
+    out["noise_cached_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     plan.close(), arena.close()
     del arena_t, vin, vout
     torch.cuda.empty_cache()
@@ -220,6 +224,10 @@ def site_step(scale, M, hpsi_ms, compile_s, dev, log):
     out["rotate_compile_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     out["rotate_ms"] = round(timed(lambda: plan.execute_device(x.data_ptr(), v.data_ptr(), 1.0, stream)), 3)
     out["rotate_enlarged_gb"] = round(rp.psi_len * 8 / 1e9, 2)
+    plan.close()
+    t0 = time.perf_counter()
+    plan = capi.Plan(arena, rp.pairs, rp.psi_len, rp.sigma_len)
+    out["rotate_cached_ms"] = round((time.perf_counter() - t0) * 1e3, 1)
     plan.close(), arena.close()
     del arena_t, x, v
     torch.cuda.empty_cache()
@@ -431,18 +439,33 @@ def main():
         if want_site:
             # a sweep creates one plan per site and destroys it before the next: the second plan of a process re-uses the
             # device buffers of the first (buffer pool in b2x_capi.cpp), so its creation is what a site pays
+            def recreate():
+                t0 = time.time()
+                pl = capi.Plan(arena, mine, full.psi_len, full.sigma_len, tile_n=args.tile_n, item_macs=args.item_macs,
+                               scratch_mb=args.scratch_mb, two_stage=args.two_stage, tile_m=args.tile_m,
+                               keep_order=args.keep_order)
+                dt_c = time.time() - t0
+                pl.close()
+                return dt_c
+
             plan.close()
-            t0 = time.time()
-            plan = capi.Plan(arena, mine, full.psi_len, full.sigma_len, tile_n=args.tile_n, item_macs=args.item_macs,
-                             scratch_mb=args.scratch_mb, two_stage=args.two_stage, tile_m=args.tile_m,
-                             keep_order=args.keep_order)
-            recycled_s = time.time() - t0
-            plan.close(), arena.close()  # free the H.psi operators before the other steps' operands are generated
+            capi.plan_cache_clear()   # -> compiled again, device buffers from the pool: a site whose structure is new
+            recycled_s = recreate()
+            cached_s = recreate()     # -> the same records again: the plan comes back from the compiled-plan cache
+            capi.plan_cache_clear()
+            arena.close()  # free the H.psi operators before the other steps' operands are generated
             del arena_t, psi_t, sigma_t
             torch.cuda.empty_cache()
             try:
                 out["site_step_ms"] = site_step(scale, M, dt / args.steps * 1e3, recycled_s, dev, log)
                 out["site_step_ms"]["hpsi_plan_create_first_ms"] = round(compile_s * 1e3, 1)
+                ss = out["site_step_ms"]
+                ss["hpsi_plan_cached_ms"] = round(cached_s * 1e3, 1)
+                ss["site_ms_ndav10_cached"] = round(10 * ss["hpsi_ms"] + ss["noise_ms"] + ss["rotate_ms"] + ss["block_ms"]
+                                                    + ss["hpsi_plan_cached_ms"] + ss["noise_cached_ms"] + ss["rotate_cached_ms"], 1)
+                out["site_step_ms"]["note_cache"] = ("hpsi_plan_compile_ms: the records are compiled (device buffers recycled); "
+                                                     "hpsi_plan_cached_ms: the same records as an earlier, destroyed plan (a "
+                                                     "site revisited at settled bond dimensions): taken from the plan cache; site_ms_ndav10_cached: such a site")
             except Exception as e:  # never lose the bench line over the extra measurement
                 out["site_step_ms"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu:

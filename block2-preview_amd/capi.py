@@ -21,6 +21,7 @@ DECLARED_SYMBOLS = [
     "b2x_arena_create", "b2x_arena_adopt_device", "b2x_arena_resolve", "b2x_arena_len",
     "b2x_arena_device_ptr", "b2x_arena_destroy",
     "b2x_plan_create", "b2x_plan_execute", "b2x_plan_get_stats", "b2x_plan_time_kernel", "b2x_plan_destroy",
+    "b2x_plan_cache_stats", "b2x_plan_cache_clear",
     "b2x_gemm_plan_create", "b2x_outer_build",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
     "b2x_vec_multi_dot", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
@@ -260,6 +261,17 @@ def outer_build(arena, terms, vin, vout, on_device=False, in_len=None, out_len=N
         in_len, out_len = vin.size, vout.size
     check(lib().b2x_outer_build(arena._h, C.c_size_t(len(terms)), _ptr(terms), _ptr(vin), C.c_size_t(in_len),
                                 C.c_size_t(out_len), _ptr(vout), C.c_int(1 if on_device else 0), C.c_void_p(int(stream))))
+
+
+def plan_cache_stats():
+    """(hits, misses, cached plans, bytes of cached work lists) of the compiled-plan cache (b2x_plan_cache_stats)"""
+    v = [C.c_uint64() for _ in range(4)]
+    check(lib().b2x_plan_cache_stats(*[C.byref(x) for x in v]))
+    return tuple(x.value for x in v)
+
+
+def plan_cache_clear():
+    check(lib().b2x_plan_cache_clear())
 
 
 class Comm:

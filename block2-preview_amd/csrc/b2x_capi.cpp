@@ -162,12 +162,43 @@ struct b2x_plan {
     double *g_sigma = nullptr;
     double g_scale = 0;
     bool graph_failed = false;
+    // what re-binding a cached plan to the next site's arena needs (plan_bind) and the cache key (see g_plan_cache)
+    uint64_t scratch_elems = 0, gslab_elems = 0, slab_elems = 0;
+    std::vector<StageCopy> stage_arena; // staged operands with an arena source: copied at every bind
+    std::vector<uint64_t> scratch_pads;
+    bool cacheable = false;
+    size_t meta_bytes = 0; // device bytes of the work lists (what a cached plan keeps resident)
+    struct Key {
+        uint64_t h1 = 0, h2 = 0, n = 0, in_len = 0, out_len = 0, arena_len = 0, arena_cap = 0;
+        int kind = 0; // 0 = pair plan, 1 = single-GEMM list
+        b2x_plan_options opt{};
+        std::vector<unsigned char> blob; // the records themselves: a hit is confirmed byte by byte
+    } key;
 };
 
-static void plan_free(b2x_plan *p) {
+// give back what belongs to ONE binding of the plan: scratch and slabs (to the pool), host-pointer staging, the graph
+static void plan_unbind(b2x_plan *p) {
     // (hipFree waits for the device; buffers that go back to the pool must be idle as well before another plan gets them)
     if (p->d_scratch || p->d_gslabs || p->d_slabs)
         (void)hipDeviceSynchronize();
+    pool_free(p->d_slabs, p->slabs_bytes), p->d_slabs = nullptr;
+    pool_free(p->d_scratch, p->scratch_bytes), p->d_scratch = nullptr;
+    pool_free(p->d_gslabs, p->gslabs_bytes), p->d_gslabs = nullptr;
+    if (p->d_psi)
+        (void)hipFree(p->d_psi), p->d_psi = nullptr;
+    if (p->d_sigma)
+        (void)hipFree(p->d_sigma), p->d_sigma = nullptr;
+    if (p->gexec)
+        (void)hipGraphExecDestroy(p->gexec), p->gexec = nullptr;
+    if (p->graph)
+        (void)hipGraphDestroy(p->graph), p->graph = nullptr;
+    p->gnodes.clear();
+    p->g_psi = nullptr, p->g_sigma = nullptr, p->graph_failed = false;
+    p->arena = nullptr;
+}
+
+static void plan_free(b2x_plan *p) {
+    plan_unbind(p);
     for (int k = 0; k < kNumClasses; k++) {
         if (p->d_parts[k])
             (void)hipFree(p->d_parts[k]);
@@ -176,7 +207,6 @@ static void plan_free(b2x_plan *p) {
     }
     if (p->d_tiles)
         (void)hipFree(p->d_tiles);
-    pool_free(p->d_slabs, p->slabs_bytes);
     if (p->d_pairs)
         (void)hipFree(p->d_pairs);
     if (p->d_gsegs)
@@ -185,43 +215,125 @@ static void plan_free(b2x_plan *p) {
         (void)hipFree(p->d_gitems);
     if (p->d_gtiles)
         (void)hipFree(p->d_gtiles);
-    pool_free(p->d_scratch, p->scratch_bytes);
     if (p->d_sum_work)
         (void)hipFree(p->d_sum_work);
     if (p->d_sum_entries)
         (void)hipFree(p->d_sum_entries);
-    pool_free(p->d_gslabs, p->gslabs_bytes);
-    if (p->d_psi)
-        (void)hipFree(p->d_psi);
-    if (p->d_sigma)
-        (void)hipFree(p->d_sigma);
     if (p->aux_stream)
         (void)hipStreamDestroy(p->aux_stream);
     if (p->ev_fork)
         (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join)
         (void)hipEventDestroy(p->ev_join);
-    if (p->gexec)
-        (void)hipGraphExecDestroy(p->gexec);
-    if (p->graph)
-        (void)hipGraphDestroy(p->graph);
     if (p->cap_stream)
         (void)hipStreamDestroy(p->cap_stream);
     delete p;
 }
 
+static thread_local size_t t_upload_bytes = 0; // bytes uploaded by upload() since the caller cleared it
 template <typename T> static int upload(T **dst, const std::vector<T> &src) {
     if (src.empty())
         return B2X_OK;
+    t_upload_bytes += src.size() * sizeof(T);
     HIPCHK(hipMalloc((void **)dst, src.size() * sizeof(T)));
     HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return B2X_OK;
 }
 
+// bind a plan (fresh, or taken from the plan cache) to an arena: scratch and slab buffers from the pool, scratch zeroed,
+// arena-sourced staged operands copied
+static int plan_bind(b2x_plan *p, const b2x_arena *arena) {
+    p->arena = arena;
+    if (p->fallback)
+        return B2X_OK;
+    if (p->scratch_elems) {
+        hipError_t e = pool_alloc((void **)&p->d_scratch, (p->scratch_elems + kSlackElems) * sizeof(double), &p->scratch_bytes);
+        if (e != hipSuccess)
+            return fail(B2X_ERR_NOMEM, std::string("hipMalloc(W scratch): ") + hipGetErrorString(e));
+        // the scratch only ever holds finite values: zeroed here, written by the kernels with products of the inputs
+        // (the padding element behind an odd-sized W slot is never written and stays zero)
+        if ((e = fill_tail(p->d_scratch, p->scratch_elems + kSlackElems)) != hipSuccess)
+            return fail(B2X_ERR_DEVICE, std::string("hipMemset(W scratch): ") + hipGetErrorString(e));
+        if (poison()) // the padding elements are zero in production; keep them so under the knob
+            for (uint64_t pad : p->scratch_pads)
+                if ((e = hipMemset(p->d_scratch + pad, 0, sizeof(double))) != hipSuccess)
+                    return fail(B2X_ERR_DEVICE, std::string("hipMemset(pad): ") + hipGetErrorString(e));
+        for (const StageCopy &sc : p->stage_arena) // staged operands with an arena source are copied now
+            if ((e = hipMemcpy(p->d_scratch + sc.dst_off, arena->dev + sc.src_off, sc.len * sizeof(double),
+                               hipMemcpyDeviceToDevice)) != hipSuccess)
+                return fail(B2X_ERR_DEVICE, std::string("staging an operand: ") + hipGetErrorString(e));
+    }
+    if (p->gslab_elems) {
+        hipError_t e = pool_alloc((void **)&p->d_gslabs, p->gslab_elems * sizeof(double), &p->gslabs_bytes);
+        if (e != hipSuccess)
+            return fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
+    }
+    if (p->slab_elems) {
+        hipError_t e = pool_alloc((void **)&p->d_slabs, p->slab_elems * sizeof(double), &p->slabs_bytes);
+        if (e != hipSuccess)
+            return fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
+    }
+    return B2X_OK;
+}
+
+// ---- cache of compiled plans --------------------------------------------------------------------------------------
+// A DMRG calculation visits the same sites sweep after sweep, and once the bond dimensions have settled the plan of a site
+// is THE SAME record list every time (same dimensions, same offsets; only the operator data differ).  The host plan
+// compiler is the largest single cost of a site below M ~ 1000 (88 ms against 10 x 0.62 ms of H.psi at M=250, DESIGN.md
+// 4d), so a destroyed plan is kept — its work lists stay in HBM, its scratch and slabs go back to the buffer pool — and
+// a later b2x_plan_create / b2x_gemm_plan_create with byte-identical records, lengths, options and arena extent takes it
+// back and only binds it to the new arena.  LRU, B2X_PLAN_CACHE_MB of work lists in total (default 8192; 0 disables).
+namespace {
+std::mutex g_cache_mu;
+std::vector<b2x_plan *> g_plan_cache; // most recently destroyed last
+size_t g_cache_bytes = 0;
+uint64_t g_cache_hits = 0, g_cache_misses = 0;
+size_t cache_cap_bytes() {
+    static const size_t cap = (size_t)(getenv("B2X_PLAN_CACHE_MB") ? atoll(getenv("B2X_PLAN_CACHE_MB")) : 8192) << 20;
+    return cap;
+}
+void make_key(b2x_plan::Key &k, int kind, const void *recs, size_t n, size_t rec_bytes, size_t in_len, size_t out_len,
+              const b2x_arena *arena, const b2x_plan_options *opt, bool with_blob) {
+    k.kind = kind, k.n = n, k.in_len = in_len, k.out_len = out_len, k.arena_len = arena->len, k.arena_cap = arena->cap;
+    k.opt = b2x_plan_options{};
+    if (opt)
+        k.opt = *opt;
+    uint64_t h1 = 0x9E3779B97F4A7C15ull, h2 = 0xC2B2AE3D27D4EB4Full;
+    const uint64_t *w = (const uint64_t *)recs; // (records are 8-byte aligned structs whose size is a multiple of 8)
+    const size_t nw = n * rec_bytes / 8;
+    for (size_t i = 0; i < nw; i++) {
+        h1 = (h1 ^ w[i]) * 0xBF58476D1CE4E5B9ull, h1 ^= h1 >> 31;
+        h2 = (h2 + w[i]) * 0x94D049BB133111EBull, h2 ^= h2 >> 29;
+    }
+    k.h1 = h1, k.h2 = h2;
+    if (with_blob)
+        k.blob.assign((const unsigned char *)recs, (const unsigned char *)recs + n * rec_bytes);
+}
+bool key_match(const b2x_plan::Key &a, const b2x_plan::Key &b, const void *recs) {
+    return a.h1 == b.h1 && a.h2 == b.h2 && a.kind == b.kind && a.n == b.n && a.in_len == b.in_len && a.out_len == b.out_len &&
+           a.arena_len == b.arena_len && a.arena_cap == b.arena_cap && memcmp(&a.opt, &b.opt, sizeof(b2x_plan_options)) == 0 &&
+           memcmp(a.blob.data(), recs, a.blob.size()) == 0;
+}
+b2x_plan *cache_take(const b2x_plan::Key &k, const void *recs) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    for (size_t i = g_plan_cache.size(); i-- > 0;)
+        if (key_match(g_plan_cache[i]->key, k, recs)) {
+            b2x_plan *p = g_plan_cache[i];
+            g_plan_cache.erase(g_plan_cache.begin() + i);
+            g_cache_bytes -= p->meta_bytes;
+            g_cache_hits++;
+            return p;
+        }
+    g_cache_misses++;
+    return nullptr;
+}
+} // namespace
+
 // upload a compiled plan (work lists + scratch / slab buffers) and hand it out
 static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPlan &cp, size_t n_pairs, const b2x_pair *pairs,
                        size_t psi_len, size_t sigma_len, const b2x_plan_options *opt) {
     int rc = B2X_OK;
+    t_upload_bytes = 0;
     b2x_plan *p = new b2x_plan();
     p->arena = arena, p->stats = cp.stats, p->psi_len = psi_len, p->sigma_len = sigma_len;
     p->kernel = opt ? opt->kernel : 0;
@@ -256,33 +368,14 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
         if (rc == B2X_OK)
             rc = upload(&p->d_sum_entries, cp.sum_entries);
         p->steps = cp.steps;
-        if (rc == B2X_OK && cp.scratch_elems) {
-            hipError_t e = pool_alloc((void **)&p->d_scratch, (cp.scratch_elems + kSlackElems) * sizeof(double), &p->scratch_bytes);
-            if (e != hipSuccess)
-                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(W scratch): ") + hipGetErrorString(e));
-            // the scratch only ever holds finite values: zeroed here, written by the kernels with products of the inputs
-            // (the padding element behind an odd-sized W slot is never written and stays zero)
-            if (rc == B2X_OK && (e = fill_tail(p->d_scratch, cp.scratch_elems + kSlackElems)) != hipSuccess)
-                rc = fail(B2X_ERR_DEVICE, std::string("hipMemset(W scratch): ") + hipGetErrorString(e));
-            if (rc == B2X_OK && poison()) // the padding elements are zero in production; keep them so under the knob
-                for (uint64_t pad : cp.scratch_pads)
-                    if ((e = hipMemset(p->d_scratch + pad, 0, sizeof(double))) != hipSuccess) {
-                        rc = fail(B2X_ERR_DEVICE, std::string("hipMemset(pad): ") + hipGetErrorString(e));
-                        break;
-                    }
-            for (const StageCopy &sc : cp.stage) { // staged operands: arena sources are copied now
-                if (rc != B2X_OK)
-                    break;
-                e = hipSuccess;
-                if (sc.src == 0)
-                    e = hipMemcpy(p->d_scratch + sc.dst_off, arena->dev + sc.src_off, sc.len * sizeof(double),
-                                  hipMemcpyDeviceToDevice);
-                if (e != hipSuccess)
-                    rc = fail(B2X_ERR_DEVICE, std::string("staging an operand: ") + hipGetErrorString(e));
-                if (sc.src == 1)
-                    p->stage_in.push_back(sc);
-            }
-        }
+        p->scratch_elems = cp.scratch_elems, p->gslab_elems = cp.gslab_elems, p->slab_elems = cp.slab_elems;
+        p->scratch_pads = cp.scratch_pads;
+        for (const StageCopy &sc : cp.stage)
+            (sc.src == 0 ? p->stage_arena : p->stage_in).push_back(sc);
+        p->meta_bytes = t_upload_bytes;
+        p->cacheable = cp.aux_work.empty(); // (operator pre-sums live in the scratch and depend on the operator data)
+        if (rc == B2X_OK)
+            rc = plan_bind(p, arena);
         if (rc == B2X_OK && !cp.aux_work.empty()) { // operator pre-sums: formed once, into the persistent head of the scratch
             OWork *dw = nullptr;
             OEntry *de = nullptr;
@@ -300,16 +393,6 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
                 (void)hipFree(dw);
             if (de)
                 (void)hipFree(de);
-        }
-        if (rc == B2X_OK && cp.gslab_elems) {
-            hipError_t e = pool_alloc((void **)&p->d_gslabs, cp.gslab_elems * sizeof(double), &p->gslabs_bytes);
-            if (e != hipSuccess)
-                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
-        }
-        if (rc == B2X_OK && cp.slab_elems) {
-            hipError_t e = pool_alloc((void **)&p->d_slabs, cp.slab_elems * sizeof(double), &p->slabs_bytes);
-            if (e != hipSuccess)
-                rc = fail(B2X_ERR_NOMEM, std::string("hipMalloc(slabs): ") + hipGetErrorString(e));
         }
     }
     if (rc != B2X_OK) {
@@ -463,12 +546,29 @@ int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, cons
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(B2X_ERR_DEVICE, "b2x_plan_create: no HIP device (the H.psi path has no CPU fallback)");
+    const bool use_cache = cache_cap_bytes() > 0 && n_pairs > 0;
+    b2x_plan::Key key;
+    if (use_cache) {
+        make_key(key, 0, pairs, n_pairs, sizeof(b2x_pair), psi_len, sigma_len, arena, opt, false);
+        if (b2x_plan *hit = cache_take(key, pairs)) {
+            int rcb = plan_bind(hit, arena);
+            if (rcb != B2X_OK) {
+                plan_free(hit);
+                return rcb;
+            }
+            *out = hit;
+            return B2X_OK;
+        }
+    }
     CompiledPlan cp;
     std::string err;
     int rc = compile_plan(n_pairs, pairs, psi_len, sigma_len, arena->len, arena->cap, opt, cp, err);
     if (rc != B2X_OK)
         return fail(rc, "b2x_plan_create: " + err);
-    return plan_upload(out, arena, cp, n_pairs, pairs, psi_len, sigma_len, opt);
+    rc = plan_upload(out, arena, cp, n_pairs, pairs, psi_len, sigma_len, opt);
+    if (rc == B2X_OK && use_cache && (*out)->cacheable && !(*out)->fallback)
+        make_key((*out)->key, 0, pairs, n_pairs, sizeof(b2x_pair), psi_len, sigma_len, arena, opt, true);
+    return rc;
 }
 
 int b2x_gemm_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_gemms, const b2x_gemm *gemms, size_t in_len,
@@ -478,12 +578,29 @@ int b2x_gemm_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_gemms,
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(B2X_ERR_DEVICE, "b2x_gemm_plan_create: no HIP device (this path has no CPU fallback)");
+    const bool use_cache = cache_cap_bytes() > 0 && n_gemms > 0;
+    b2x_plan::Key key;
+    if (use_cache) {
+        make_key(key, 1, gemms, n_gemms, sizeof(b2x_gemm), in_len, out_len, arena, opt, false);
+        if (b2x_plan *hit = cache_take(key, gemms)) {
+            int rcb = plan_bind(hit, arena);
+            if (rcb != B2X_OK) {
+                plan_free(hit);
+                return rcb;
+            }
+            *out = hit;
+            return B2X_OK;
+        }
+    }
     CompiledPlan cp;
     std::string err;
     int rc = compile_gemm_list(n_gemms, gemms, in_len, out_len, arena->len, arena->cap, opt, cp, err);
     if (rc != B2X_OK)
         return fail(rc, "b2x_gemm_plan_create: " + err);
-    return plan_upload(out, arena, cp, 0, nullptr, in_len, out_len, nullptr);
+    rc = plan_upload(out, arena, cp, 0, nullptr, in_len, out_len, nullptr);
+    if (rc == B2X_OK && use_cache && (*out)->cacheable)
+        make_key((*out)->key, 1, gemms, n_gemms, sizeof(b2x_gemm), in_len, out_len, arena, opt, true);
+    return rc;
 }
 
 // one stage of a super-step: both tile classes, the short one on the plan's own stream beside the tall one
@@ -710,8 +827,51 @@ int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, 
 }
 
 int b2x_plan_destroy(b2x_plan *p) {
-    if (p)
+    if (!p)
+        return B2X_OK;
+    if (p->key.blob.empty() || p->meta_bytes > cache_cap_bytes()) { // not cacheable (or the cache is off)
         plan_free(p);
+        return B2X_OK;
+    }
+    plan_unbind(p);
+    std::vector<b2x_plan *> evict;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        g_plan_cache.push_back(p);
+        g_cache_bytes += p->meta_bytes;
+        while (g_cache_bytes > cache_cap_bytes() && g_plan_cache.size() > 1) { // least recently destroyed first
+            g_cache_bytes -= g_plan_cache.front()->meta_bytes;
+            evict.push_back(g_plan_cache.front());
+            g_plan_cache.erase(g_plan_cache.begin());
+        }
+    }
+    for (b2x_plan *q : evict)
+        plan_free(q);
+    return B2X_OK;
+}
+
+int b2x_plan_cache_stats(uint64_t *hits, uint64_t *misses, uint64_t *plans, uint64_t *bytes) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (hits)
+        *hits = g_cache_hits;
+    if (misses)
+        *misses = g_cache_misses;
+    if (plans)
+        *plans = g_plan_cache.size();
+    if (bytes)
+        *bytes = g_cache_bytes;
+    return B2X_OK;
+}
+
+int b2x_plan_cache_clear(void) {
+    std::vector<b2x_plan *> all;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        all.swap(g_plan_cache);
+        g_cache_bytes = 0;
+    }
+    for (b2x_plan *q : all)
+        plan_free(q);
     return B2X_OK;
 }
 

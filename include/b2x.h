@@ -142,6 +142,13 @@ int b2x_plan_get_stats(const b2x_plan *p, b2x_plan_stats *st);
 int b2x_plan_time_kernel(b2x_plan *p, const double *psi_dev, double *sigma_dev, int n, void *stream,
                          double *avg_ms_main, double *avg_ms_total);
 int b2x_plan_destroy(b2x_plan *p);
+/* Compiled plans are cached: b2x_plan_destroy keeps the plan's work lists in HBM (its scratch and slabs go back to a buffer
+ * pool), and a later b2x_plan_create / b2x_gemm_plan_create with byte-identical records, lengths, options and arena extent
+ * takes the plan back instead of compiling again — the case of every site of a sweep once the bond dimensions have settled
+ * (the reference rebuilds its plan in precompute() every time, effective_hamiltonian.hpp:224-251).  LRU, bounded by
+ * B2X_PLAN_CACHE_MB MiB of work lists (default 8192; 0 disables).  Counters since process start; clear() frees the cache. */
+int b2x_plan_cache_stats(uint64_t *hits, uint64_t *misses, uint64_t *plans, uint64_t *bytes);
+int b2x_plan_cache_clear(void);
 
 /* single-GEMM lists (perturbative noise; partial multiplies) ------------------------------------------------
  * Replaces: the batch[1]-only lists that BatchGEMMSeq::multiply / three_rotate_tr_left / three_rotate_tr_right
