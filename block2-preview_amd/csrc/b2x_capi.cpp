@@ -978,10 +978,12 @@ int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term
 
 // ---------------------------------------------------------------------------------- vectors
 static double *g_dot_partial = nullptr, *g_dot_out = nullptr;
+static double *g_dot_host = nullptr; // pinned: the few result doubles of every dot product cross PCIe without a staging copy
 static int dot_scratch() {
     if (!g_dot_partial) {
         HIPCHK(hipMalloc((void **)&g_dot_partial, 64 * 256 * sizeof(double)));
         HIPCHK(hipMalloc((void **)&g_dot_out, 64 * sizeof(double)));
+        HIPCHK(hipHostMalloc((void **)&g_dot_host, 64 * sizeof(double), hipHostMallocDefault));
     }
     return B2X_OK;
 }
@@ -994,8 +996,9 @@ int b2x_vec_multi_dot(const double *const *vs, int nv, const double *x, size_t n
         return rc;
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(launch_multidot(vs, nv, x, n, g_dot_partial, g_dot_out, st));
-    HIPCHK(hipMemcpyAsync(host_result, g_dot_out, nv * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(g_dot_host, g_dot_out, nv * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    memcpy(host_result, g_dot_host, nv * sizeof(double));
     return B2X_OK;
 }
 int b2x_vec_dot(const double *x, const double *y, size_t n, double *host_result, void *stream) {

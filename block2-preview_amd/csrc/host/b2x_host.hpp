@@ -615,54 +615,136 @@ struct DeviceVector {
     void download(double *h) const { check(b2x_memcpy_d2h(h, p, n * 8)); }
 };
 
-// symmetric eigenproblem of the (<= 50 x 50) subspace matrix: cyclic Jacobi, eigenvalues ascending,
-// row j of `a` = eigenvector j on return (the layout davidson uses: sigma_j' = sum_i alpha(j,i) sigma_i)
+// symmetric eigenproblem of the (<= 63 x 63) subspace matrix (the reference calls LAPACK dsyev here): Householder
+// reduction to tridiagonal form, then implicit-shift QL; eigenvalues ascending, row j of `a` = eigenvector j on return
+// (the layout davidson uses).  Only the lower triangle of `a` is read.  (A cyclic Jacobi solver stood here first: at
+// m ~ 30 it cost 0.8 ms per Davidson iteration, more than the whole vector algebra.)
 inline void small_eigs(std::vector<double> &a, std::vector<double> &w, int m) {
-    std::vector<double> v((size_t)m * m, 0.0);
-    for (int i = 0; i < m; i++)
-        v[(size_t)i * m + i] = 1.0;
-    for (int i = 0; i < m; i++)
-        for (int j = i + 1; j < m; j++)
-            a[(size_t)i * m + j] = a[(size_t)j * m + i]; // lower triangle was filled
-    for (int sweep = 0; sweep < 100; sweep++) {
-        double off = 0;
-        for (int i = 0; i < m; i++)
+    const int n = m;
+    std::vector<double> V((size_t)n * n), d(n), e(n);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++)
+            V[(size_t)i * n + j] = V[(size_t)j * n + i] = a[(size_t)i * n + j];
+    auto v = [&](int i, int j) -> double & { return V[(size_t)i * n + j]; };
+    // ---- Householder tridiagonalisation (V accumulates the transformation) ----
+    for (int j = 0; j < n; j++)
+        d[j] = v(n - 1, j);
+    for (int i = n - 1; i > 0; i--) {
+        double scale = 0.0, h = 0.0;
+        for (int k = 0; k < i; k++)
+            scale += std::fabs(d[k]);
+        if (scale == 0.0) {
+            e[i] = d[i - 1];
             for (int j = 0; j < i; j++)
-                off += a[(size_t)i * m + j] * a[(size_t)i * m + j];
-        if (off < 1e-300)
-            break;
-        for (int p = 0; p < m; p++)
-            for (int q = p + 1; q < m; q++) {
-                double apq = a[(size_t)p * m + q];
-                if (std::fabs(apq) < 1e-300)
-                    continue;
-                double theta = (a[(size_t)q * m + q] - a[(size_t)p * m + p]) / (2.0 * apq);
-                double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-                double cs = 1.0 / std::sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < m; k++) {
-                    double akp = a[(size_t)k * m + p], akq = a[(size_t)k * m + q];
-                    a[(size_t)k * m + p] = cs * akp - sn * akq, a[(size_t)k * m + q] = sn * akp + cs * akq;
-                }
-                for (int k = 0; k < m; k++) {
-                    double apk = a[(size_t)p * m + k], aqk = a[(size_t)q * m + k];
-                    a[(size_t)p * m + k] = cs * apk - sn * aqk, a[(size_t)q * m + k] = sn * apk + cs * aqk;
-                }
-                for (int k = 0; k < m; k++) {
-                    double vkp = v[(size_t)k * m + p], vkq = v[(size_t)k * m + q];
-                    v[(size_t)k * m + p] = cs * vkp - sn * vkq, v[(size_t)k * m + q] = sn * vkp + cs * vkq;
-                }
+                d[j] = v(i - 1, j), v(i, j) = 0.0, v(j, i) = 0.0;
+        } else {
+            for (int k = 0; k < i; k++)
+                d[k] /= scale, h += d[k] * d[k];
+            double f = d[i - 1], g = std::sqrt(h);
+            if (f > 0)
+                g = -g;
+            e[i] = scale * g, h -= f * g, d[i - 1] = f - g;
+            for (int j = 0; j < i; j++)
+                e[j] = 0.0;
+            for (int j = 0; j < i; j++) {
+                f = d[j], v(j, i) = f, g = e[j] + v(j, j) * f;
+                for (int k = j + 1; k <= i - 1; k++)
+                    g += v(k, j) * d[k], e[k] += v(k, j) * f;
+                e[j] = g;
             }
+            f = 0.0;
+            for (int j = 0; j < i; j++)
+                e[j] /= h, f += e[j] * d[j];
+            const double hh = f / (h + h);
+            for (int j = 0; j < i; j++)
+                e[j] -= hh * d[j];
+            for (int j = 0; j < i; j++) {
+                f = d[j], g = e[j];
+                for (int k = j; k <= i - 1; k++)
+                    v(k, j) -= (f * e[k] + g * d[k]);
+                d[j] = v(i - 1, j), v(i, j) = 0.0;
+            }
+        }
+        d[i] = h;
     }
-    std::vector<int> idx(m);
-    for (int i = 0; i < m; i++)
+    for (int i = 0; i < n - 1; i++) {
+        v(n - 1, i) = v(i, i), v(i, i) = 1.0;
+        const double h = d[i + 1];
+        if (h != 0.0) {
+            for (int k = 0; k <= i; k++)
+                d[k] = v(k, i + 1) / h;
+            for (int j = 0; j <= i; j++) {
+                double g = 0.0;
+                for (int k = 0; k <= i; k++)
+                    g += v(k, i + 1) * v(k, j);
+                for (int k = 0; k <= i; k++)
+                    v(k, j) -= g * d[k];
+            }
+        }
+        for (int k = 0; k <= i; k++)
+            v(k, i + 1) = 0.0;
+    }
+    for (int j = 0; j < n; j++)
+        d[j] = v(n - 1, j), v(n - 1, j) = 0.0;
+    if (n > 0)
+        v(n - 1, n - 1) = 1.0, e[0] = 0.0;
+    // ---- implicit-shift QL on the tridiagonal matrix (d, e) ----
+    for (int i = 1; i < n; i++)
+        e[i - 1] = e[i];
+    if (n > 0)
+        e[n - 1] = 0.0;
+    double f = 0.0, tst1 = 0.0;
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n; l++) {
+        tst1 = std::max(tst1, std::fabs(d[l]) + std::fabs(e[l]));
+        int mm = l;
+        while (mm < n) {
+            if (std::fabs(e[mm]) <= eps * tst1)
+                break;
+            mm++;
+        }
+        if (mm > l) {
+            int iter = 0;
+            do {
+                iter++;
+                double g = d[l], p = (d[l + 1] - g) / (2.0 * e[l]), r = std::hypot(p, 1.0);
+                if (p < 0)
+                    r = -r;
+                d[l] = e[l] / (p + r), d[l + 1] = e[l] * (p + r);
+                const double dl1 = d[l + 1];
+                double h = g - d[l];
+                for (int i = l + 2; i < n; i++)
+                    d[i] -= h;
+                f += h;
+                p = d[mm];
+                double c = 1.0, c2 = c, c3 = c, s = 0.0, s2 = 0.0;
+                const double el1 = e[l + 1];
+                for (int i = mm - 1; i >= l; i--) {
+                    c3 = c2, c2 = c, s2 = s;
+                    g = c * e[i], h = c * p, r = std::hypot(p, e[i]);
+                    e[i + 1] = s * r, s = e[i] / r, c = p / r, p = c * d[i] - s * g;
+                    d[i + 1] = h + s * (c * g + s * d[i]);
+                    for (int k = 0; k < n; k++) {
+                        h = v(k, i + 1);
+                        v(k, i + 1) = s * v(k, i) + c * h, v(k, i) = c * v(k, i) - s * h;
+                    }
+                }
+                p = -s * s2 * c3 * el1 * e[l] / dl1;
+                e[l] = s * p, d[l] = c * p;
+            } while (std::fabs(e[l]) > eps * tst1 && iter < 200);
+        }
+        d[l] += f, e[l] = 0.0;
+    }
+    std::vector<int> idx(n);
+    for (int i = 0; i < n; i++)
         idx[i] = i;
-    std::sort(idx.begin(), idx.end(), [&](int x, int y) { return a[(size_t)x * m + x] < a[(size_t)y * m + y]; });
-    w.resize(m);
-    std::vector<double> out((size_t)m * m);
-    for (int j = 0; j < m; j++) {
-        w[j] = a[(size_t)idx[j] * m + idx[j]];
-        for (int i = 0; i < m; i++)
-            out[(size_t)j * m + i] = v[(size_t)i * m + idx[j]];
+    std::sort(idx.begin(), idx.end(), [&](int x, int y) { return d[x] < d[y]; });
+    w.resize(n);
+    std::vector<double> out((size_t)n * n);
+    for (int j = 0; j < n; j++) {
+        w[j] = d[idx[j]];
+        for (int i = 0; i < n; i++)
+            out[(size_t)j * n + i] = v(i, idx[j]);
     }
     a.swap(out);
 }
@@ -734,24 +816,35 @@ struct IterativeMatrixFunctions {
         if (deflation_max_size > 63)
             deflation_max_size = 63;
         const int M = deflation_max_size;
+        // psi-sized work vectors come from slabs of 8 (one hipMalloc per slab: a device allocation per new subspace vector
+        // costs more than the vector algebra of an iteration at small |psi|)
         std::vector<std::unique_ptr<DeviceVector>> store;
+        const size_t n_pad = (n + 31) & ~(size_t)31;
+        size_t slab_left = 0;
+        double *slab_next = nullptr;
         auto mk = [&]() {
-            store.emplace_back(new DeviceVector(n));
-            return store.back()->p;
+            if (slab_left == 0) {
+                store.emplace_back(new DeviceVector(8 * n_pad));
+                slab_next = store.back()->p, slab_left = 8;
+            }
+            double *r = slab_next;
+            slab_next += n_pad, slab_left--;
+            return r;
         };
         // the subspace vectors are allocated as the subspace grows (the reference holds 2 M vectors up front, :902-907;
-        // typical runs converge with m << M, and 4 M + 2 eager psi-sized vectors would be 15 GB at the M=4000 psi)
-        std::vector<double *> bs(M, nullptr), sg(M, nullptr), tb(M, nullptr), ts(M, nullptr);
+        // typical runs converge with m << M)
+        std::vector<double *> bs(M, nullptr), sg(M, nullptr);
         auto ensure = [&](int i) {
             if (bs[i] == nullptr)
-                bs[i] = mk(), sg[i] = mk(), tb[i] = mk(), ts[i] = mk();
+                bs[i] = mk(), sg[i] = mk();
         };
         for (int i = 0; i < k; i++)
             ensure(i);
-        double *q = mk(), *t = mk();
-        auto dot = [&](const double *x, const double *y) {
+        double *q = mk(), *t = mk(), *x = mk(); // residual / work vector / current Ritz vector
+        std::vector<double *> dfl_b, dfl_s;     // work vectors of a deflation step
+        auto dot = [&](const double *u, const double *v) {
             double r;
-            check(b2x_vec_dot(x, y, n, &r, nullptr));
+            check(b2x_vec_dot(u, v, n, &r, nullptr));
             return r;
         };
         std::vector<double> or_normsqs(nor);
@@ -761,10 +854,26 @@ struct IterativeMatrixFunctions {
                     check(b2x_vec_axpy(-dot(ors[j], ors[i]) / or_normsqs[j], ors[j], ors[i], n, nullptr));
             or_normsqs[i] = dot(ors[i], ors[i]);
         }
-        auto project_ors = [&](double *x) {
+        auto project_ors = [&](double *v) {
             for (int j = 0; j < nor; j++)
                 if (std::fabs(or_normsqs[j]) > 1E-14)
-                    check(b2x_vec_axpy(-dot(ors[j], x) / or_normsqs[j], ors[j], x, n, nullptr));
+                    check(b2x_vec_axpy(-dot(ors[j], v) / or_normsqs[j], ors[j], v, n, nullptr));
+        };
+        // v -= sum_{j < m} <b_j, v> b_j: ONE multi-dot and ONE linear combination per pass (the reference's loop of m
+        // dot / axpy pairs, :1143-1144, costs m launches and m host round trips on a device), two passes for the
+        // orthogonality a one-pass classical Gram-Schmidt loses.  Result in `v` (the work vector w is swapped in).
+        std::vector<double> gs_c(M + 1);
+        auto orthogonalise = [&](double *&v, double *&w, int m_) {
+            for (int pass = 0; pass < 2 && m_ > 0; pass++) {
+                std::vector<const double *> ptrs(bs.begin(), bs.begin() + m_);
+                check(b2x_vec_multi_dot(ptrs.data(), m_, v, n, gs_c.data(), nullptr));
+                for (int j = 0; j < m_; j++)
+                    gs_c[j] = -gs_c[j];
+                gs_c[m_] = 1.0;
+                ptrs.push_back(v);
+                check(b2x_vec_lincomb(ptrs.data(), m_ + 1, gs_c.data(), w, n, nullptr));
+                std::swap(v, w);
+            }
         };
         for (int i = 0; i < k; i++)
             check(b2x_vec_copy(vs_dev[i], bs[i], n, nullptr));
@@ -789,11 +898,35 @@ struct IterativeMatrixFunctions {
                                          " for Davidson unitary to all given states!");
             check(b2x_vec_scal(1.0 / nrm, bs[i], n, nullptr));
         }
-        std::vector<double> eigvals(k), ld;
+        // The reference rotates ALL basis vectors and their sigmas into the Ritz basis in every iteration (:1000-1022:
+        // 2 m^2 axpy-like passes over psi-sized vectors).  The Ritz pairs depend on the subspace only, so the basis stays
+        // as it is here and the projected matrix H_ij = <b_i, sigma_j> is kept on the host (one new column per new
+        // vector); the Ritz vector and the residual of the root in work are two linear combinations.  Same subspace, same
+        // Ritz values and residuals up to rounding; per iteration O(m) instead of O(m^2) vector passes and a fixed
+        // number of launches (tools/davidson_overhead.py: 2.5 -> ms of overhead per iteration at |psi| = 36 k).
+        std::vector<double> H((size_t)M * M, 0.0), alpha, ld, row(M), coef(M + 1);
+        std::vector<double> eigvals(k);
         std::vector<int> idx(M);
         int ck = 0, msig = 0, xiter = 0;
         double qq = 0;
         auto thrd = [&](double e) { return conv_thrd + e * e * rel_conv_thrd * rel_conv_thrd; };
+        // x = Ritz vector of root r (coefficients alpha row r), q = H x - theta x
+        auto ritz_residual = [&](int r) {
+            std::vector<const double *> pb(bs.begin(), bs.begin() + m), ps(sg.begin(), sg.begin() + m);
+            check(b2x_vec_lincomb(pb.data(), m, &alpha[(size_t)r * m], x, n, nullptr));
+            for (int j = 0; j < m; j++)
+                coef[j] = alpha[(size_t)r * m + j];
+            coef[m] = -ld[r];
+            ps.push_back(x);
+            check(b2x_vec_lincomb(ps.data(), m + 1, coef.data(), q, n, nullptr));
+        };
+        static const bool prof = getenv("B2X_DAV_PROFILE") != nullptr;
+        double t_op = 0, t_eig = 0;
+        auto now = []() { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return std::chrono::duration<double>(b - a).count();
+        };
+        const auto t_begin = now();
         while (xiter < max_iter && (soft_max_iter == -1 || xiter < soft_max_iter)) {
             xiter++;
             if (pcomm != nullptr && xiter != 1)
@@ -801,28 +934,29 @@ struct IterativeMatrixFunctions {
                     pcomm->broadcast(bs[i], n);
             for (int i = msig; i < m; i++, msig++) {
                 check(b2x_vec_zero(sg[i], n, nullptr));
+                const auto t0 = now();
                 op(bs[i], sg[i]);
+                if (prof) {
+                    check(b2x_device_sync());
+                    t_op += secs(t0, now());
+                }
                 for (int j = 0; j < nwg; j++)
                     check(b2x_vec_axpy(dot(ors[j], bs[i]) * proj_weights[j], ors[j], sg[i], n, nullptr));
+                // new column of the projected matrix: H(j, i) = <b_j, sigma_i>, j <= i (H is symmetric)
+                std::vector<const double *> ptrs(bs.begin(), bs.begin() + i + 1);
+                check(b2x_vec_multi_dot(ptrs.data(), i + 1, sg[i], n, row.data(), nullptr));
+                for (int j = 0; j <= i; j++)
+                    H[(size_t)j * M + i] = H[(size_t)i * M + j] = row[j];
             }
             // Rayleigh-Ritz in the current basis
-            std::vector<double> alpha((size_t)m * m, 0.0), row(m);
-            for (int j = 0; j < m; j++) { // alpha(i, j) = <b_i, sigma_j>, i >= j
-                std::vector<const double *> ptrs(bs.begin() + j, bs.begin() + m);
-                check(b2x_vec_multi_dot(ptrs.data(), m - j, sg[j], n, row.data(), nullptr));
-                for (int i = j; i < m; i++)
-                    alpha[(size_t)i * m + j] = row[i - j];
-            }
-            small_eigs(alpha, ld, m);
-            // sigma[:] = alpha sigma[:],  b[:] = alpha b[:]   (full rotation, as the reference does)
+            alpha.assign((size_t)m * m, 0.0);
+            for (int i = 0; i < m; i++)
+                for (int j = 0; j <= i; j++)
+                    alpha[(size_t)i * m + j] = H[(size_t)i * M + j];
             {
-                std::vector<const double *> ps(sg.begin(), sg.begin() + m), pb(bs.begin(), bs.begin() + m);
-                for (int j = 0; j < m; j++) {
-                    check(b2x_vec_lincomb(ps.data(), m, &alpha[(size_t)j * m], ts[j], n, nullptr));
-                    check(b2x_vec_lincomb(pb.data(), m, &alpha[(size_t)j * m], tb[j], n, nullptr));
-                }
-                for (int j = 0; j < m; j++)
-                    std::swap(sg[j], ts[j]), std::swap(bs[j], tb[j]);
+                const auto t0 = now();
+                small_eigs(alpha, ld, m); // row r of alpha = eigenvector r (ascending eigenvalues)
+                t_eig += secs(t0, now());
             }
             for (int i = 0; i < m; i++)
                 idx[i] = i;
@@ -842,17 +976,14 @@ struct IterativeMatrixFunctions {
                     return shift > ld[i] ? shift - ld[i] > shift - ld[j] : ld[i] - shift < ld[j] - shift;
                 });
             for (int i = 0; i < ck; i++) { // re-check the roots already counted as converged
-                const int ii = idx[i];
-                check(b2x_vec_copy(sg[ii], q, n, nullptr));
-                check(b2x_vec_axpy(-ld[ii], bs[ii], q, n, nullptr));
-                if (std::fabs(dot(q, q)) >= thrd(ld[ii])) {
+                ritz_residual(idx[i]);
+                if (std::fabs(dot(q, q)) >= thrd(ld[idx[i]])) {
                     ck = i;
                     break;
                 }
             }
             const int ick = idx[ck];
-            check(b2x_vec_copy(sg[ick], q, n, nullptr));
-            check(b2x_vec_axpy(-ld[ick], bs[ick], q, n, nullptr));
+            ritz_residual(ick);
             project_ors(q);
             qq = dot(q, q);
             if (iprint)
@@ -860,9 +991,11 @@ struct IterativeMatrixFunctions {
             if (davidson_type & DavidsonTypes::DavidsonPrecond) // davidson_precondition (:66-72)
                 check(b2x_vec_precondition(q, aa_dev, ld[ick], n, nullptr));
             else if (!(davidson_type & DavidsonTypes::NoPrecond)) { // olsen_precondition (:93-108)
-                check(b2x_vec_olsen_prepare(q, t, bs[ick], aa_dev, ld[ick], n, nullptr));
-                double cq = dot(bs[ick], q), ct = dot(bs[ick], t);
-                check(b2x_vec_axpy(-cq / ct, t, q, n, nullptr));
+                check(b2x_vec_olsen_prepare(q, t, x, aa_dev, ld[ick], n, nullptr));
+                const double *qt[2] = {q, t};
+                double cqt[2];
+                check(b2x_vec_multi_dot(qt, 2, x, n, cqt, nullptr));
+                check(b2x_vec_axpy(-cqt[0] / cqt[1], t, q, n, nullptr));
             }
             eigvals.resize(ck + 1);
             for (int i = 0; i <= ck; i++)
@@ -872,20 +1005,31 @@ struct IterativeMatrixFunctions {
                 if (ck == k)
                     break;
             } else {
-                if (m >= deflation_max_size) {
-                    m = msig = deflation_min_size;
-                    if ((davidson_type & DavidsonTypes::LessThan) || (davidson_type & DavidsonTypes::GreaterThan) ||
-                        (davidson_type & DavidsonTypes::CloseTo)) { // keep the roots that lead the chosen order (:1113-1141)
-                        for (int j = 0; j < m; j++) {
-                            check(b2x_vec_copy(bs[idx[j]], tb[j], n, nullptr));
-                            check(b2x_vec_copy(sg[idx[j]], ts[j], n, nullptr));
-                        }
-                        for (int j = 0; j < m; j++)
-                            std::swap(bs[j], tb[j]), std::swap(sg[j], ts[j]), idx[j] = j;
+                if (m >= deflation_max_size) { // collapse to the leading Ritz vectors (:1108-1141)
+                    const int keep = deflation_min_size;
+                    std::vector<const double *> pb(bs.begin(), bs.begin() + m), ps(sg.begin(), sg.begin() + m);
+                    if ((int)dfl_b.size() < keep)
+                        for (int j = (int)dfl_b.size(); j < keep; j++)
+                            dfl_b.push_back(mk()), dfl_s.push_back(mk());
+                    for (int j = 0; j < keep; j++) {
+                        check(b2x_vec_lincomb(pb.data(), m, &alpha[(size_t)idx[j] * m], dfl_b[j], n, nullptr));
+                        check(b2x_vec_lincomb(ps.data(), m, &alpha[(size_t)idx[j] * m], dfl_s[j], n, nullptr));
                     }
+                    std::vector<double> th(keep);
+                    for (int j = 0; j < keep; j++) {
+                        th[j] = ld[idx[j]];
+                        check(b2x_vec_copy(dfl_b[j], bs[j], n, nullptr));
+                        check(b2x_vec_copy(dfl_s[j], sg[j], n, nullptr));
+                    }
+                    // in the new basis the projected matrix is diag(theta) and the Ritz vectors are the basis vectors
+                    std::fill(H.begin(), H.end(), 0.0);
+                    alpha.assign((size_t)keep * keep, 0.0);
+                    ld.assign(th.begin(), th.end());
+                    for (int j = 0; j < keep; j++)
+                        H[(size_t)j * M + j] = th[j], alpha[(size_t)j * keep + j] = 1.0, idx[j] = j;
+                    m = msig = keep;
                 }
-                for (int j = 0; j < m; j++)
-                    check(b2x_vec_axpy(-dot(bs[j], q), bs[j], q, n, nullptr));
+                orthogonalise(q, t, m);
                 project_ors(q);
                 check(b2x_vec_scal(1.0 / std::sqrt(dot(q, q)), q, n, nullptr));
                 ensure(m);
@@ -899,12 +1043,25 @@ struct IterativeMatrixFunctions {
             eigvals.resize(k, 0);
         if (xiter == max_iter)
             throw std::runtime_error("Davidson: only " + std::to_string(ck) + " converged!");
-        for (int i = 0; i < k; i++)
-            check(b2x_vec_copy(bs[idx[i]], vs_dev[i], n, nullptr));
+        if (!alpha.empty() && (int)ld.size() >= k) { // eigenvectors = Ritz vectors of the last Rayleigh-Ritz step
+            const int mr = (int)ld.size();
+            std::vector<const double *> pb(bs.begin(), bs.begin() + mr);
+            std::vector<double *> outv(k);
+            for (int i = 0; i < k; i++) {
+                outv[i] = mk();
+                check(b2x_vec_lincomb(pb.data(), mr, &alpha[(size_t)idx[i] * mr], outv[i], n, nullptr));
+            }
+            for (int i = 0; i < k; i++)
+                check(b2x_vec_copy(outv[i], vs_dev[i], n, nullptr));
+        }
         if (pcomm != nullptr)
             for (int i = 0; i < k; i++)
                 pcomm->broadcast(vs_dev[i], n);
         check(b2x_device_sync());
+        if (prof)
+            fprintf(stderr, "davidson: %d iterations %.3f ms each: H.psi (synchronised) %.3f, host eigensolver %.3f, vector algebra %.3f\n",
+                    xiter, secs(t_begin, now()) / xiter * 1e3, t_op / xiter * 1e3, t_eig / xiter * 1e3,
+                    (secs(t_begin, now()) - t_op - t_eig) / xiter * 1e3);
         ndav = xiter;
         return eigvals;
     }

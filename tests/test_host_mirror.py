@@ -31,7 +31,7 @@ def test_three_rotate_needs_scalar_factor(host):
         seq.three_rotate((0, 2, 2), (0, 2, 2), x, False, x, False, x, False, x, False, True, 1.0, 0)
 
 
-@pytest.mark.parametrize("m", [1, 2, 7, 30])
+@pytest.mark.parametrize("m", [1, 2, 7, 30, 63])
 def test_small_eigs_matches_lapack(host, m):
     """subspace eigensolver of davidson: ascending eigenvalues, row j = eigenvector j (alpha(j, i))"""
     rng = np.random.default_rng(m)
@@ -44,3 +44,17 @@ def test_small_eigs_matches_lapack(host, m):
     assert np.allclose(w, w_ref, atol=1e-11)
     for j in range(m):
         assert np.allclose(a @ v[j], w[j] * v[j], atol=1e-9)
+
+
+def test_small_eigs_degenerate_and_diagonal(host):
+    """already diagonal matrices (the state after a Davidson deflation) and repeated eigenvalues"""
+    d = np.diag([3.0, -1.0, 2.0, 2.0, 2.0, 0.0])
+    w, v = host.small_eigs(d.ravel().tolist(), 6)
+    assert np.allclose(w, [-1, 0, 2, 2, 2, 3]) and np.allclose(np.array(v).reshape(6, 6) @ np.array(v).reshape(6, 6).T, np.eye(6))
+    rng = np.random.default_rng(0)
+    q, _ = np.linalg.qr(rng.standard_normal((12, 12)))
+    a = q @ np.diag([1.0] * 5 + [2.0] * 4 + [-3.0, 7.0, 7.0]) @ q.T
+    w, v = host.small_eigs(np.tril(a).ravel().tolist(), 12)
+    v = np.array(v).reshape(12, 12)
+    assert np.allclose(w, sorted([1.0] * 5 + [2.0] * 4 + [-3.0, 7.0, 7.0]), atol=1e-12)
+    assert np.allclose(v @ v.T, np.eye(12), atol=1e-12) and np.allclose(v @ a @ v.T, np.diag(w), atol=1e-11)
