@@ -297,11 +297,20 @@ class DMRG:
         out = np.zeros(int(d["meta"][7]))
         base = int(d["mps.off"][0])
         n, tl, tw, pg = _fields(kinfo["q"])
-        dn, _, _, dpg = _fields(np.array([kinfo["dq"]], np.uint64))
+        dn, _, dtw, dpg = _fields(np.array([kinfo["dq"]], np.uint64))
         an, _, atw, apg = _fields(ainfo["q"])
-        if right:  # right label of a psi block: -ket  ->  (-n, twos, pg)
+        if self.sym == "sz":
+            # SZ (src/core/symmetry.hpp:654-731): 2Sz is a SIGNED 16-bit field and adds like n; the stored label of a psi
+            # block is its (negated) right label, the left one is label + dq
+            sgn = lambda t: np.where(t >= 32768, t - 65536, t)
+            tw, dtw, atw = sgn(tw), sgn(dtw), sgn(atw)
+            if right:
+                bn, btw, bpg = -n, -tw, pg
+            else:
+                bn, btw, bpg = n + dn[0], tw + dtw[0], pg ^ dpg[0]
+        elif right:  # SU2: right label of a psi block: -ket  ->  (-n, twos, pg)
             bn, btw, bpg = -n, tw, pg
-        else:      # left label: get_bra(dq)  ->  (n + dq.n, twos_low, pg ^ dq.pg)
+        else:        # left label: get_bra(dq)  ->  (n + dq.n, twos_low, pg ^ dq.pg)
             bn, btw, bpg = n + dn[0], tl, pg ^ dpg[0]
         for s in range(len(ainfo["q"])):
             sel = np.nonzero((bn == an[s]) & (btw == atw[s]) & (bpg == apg[s]))[0]

@@ -32,3 +32,22 @@ def test_n2_su2_two_sweeps_site_energies(gpu):
     assert worst < 1e-7
     assert abs(e1[-1] - (-107.654122447525)) < 1e-7
     assert abs(e0[0] - (-99.0104099582)) < 1e-7  # far from converged at the first site: the chain, not the answer, is tested
+
+
+def test_h10_sz_two_sweeps_site_energies(gpu):
+    """the same gate on an SZ system: H10/STO-6G R=1.8 (the molecule of BASELINE configs[1]) at M=100, sweeps 0-1 of one
+    reference run (tests/golden/chain_h10sz: 114 events); every site energy to 1e-7 Ha"""
+    from block2_preview_amd.sweep import DMRG, ChainFixture
+
+    fx = ChainFixture(os.path.join(GOLDEN, "chain_h10sz", "h10c"))
+    assert len(fx.events) == 114 and len(fx.ref_energy) == 18
+    dm = DMRG(fx, "sz")
+    dm.init_environments()
+    assert dm.n_sites == 10
+    e0 = dm.sweep(0, True)
+    e1 = dm.sweep(1, False)
+    assert fx.pos == len(fx.events)
+    worst = max(abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items())
+    print("site energies", ["%.10f" % e for e in e0 + e1], "worst |dE| = %.2e" % worst)
+    assert worst < 1e-7
+    assert abs(min(e0 + e1) - fx.final_energy) < 1e-7
