@@ -34,9 +34,10 @@ def test_n2_su2_two_sweeps_site_energies(gpu):
     assert abs(e0[0] - (-99.0104099582)) < 1e-7  # far from converged at the first site: the chain, not the answer, is tested
 
 
-def test_h10_sz_two_sweeps_site_energies(gpu):
-    """the same gate on an SZ system: H10/STO-6G R=1.8 (the molecule of BASELINE configs[1]) at M=100, sweeps 0-1 of one
-    reference run (tests/golden/chain_h10sz: 114 events); every site energy to 1e-7 Ha"""
+def test_h10_sz_m500_site_energies_and_known_answer(gpu):
+    """the same gate on BASELINE configs[1]: H10/STO-6G R=1.8, SZ, M=500 — the two sweeps after which the reference run
+    converges (tests/golden/chain_h10sz: 114 events); every site energy to 1e-7 Ha and the final energy equal to block2's
+    in-tree answer -5.424385376237 (the reference run of the fixture gives -5.4243853763327)"""
     from block2_preview_amd.sweep import DMRG, ChainFixture
 
     fx = ChainFixture(os.path.join(GOLDEN, "chain_h10sz", "h10c"))
@@ -47,7 +48,13 @@ def test_h10_sz_two_sweeps_site_energies(gpu):
     e0 = dm.sweep(0, True)
     e1 = dm.sweep(1, False)
     assert fx.pos == len(fx.events)
-    worst = max(abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items())
+    # The very first site is the one place where the reference has only its random starting MPS as Davidson guess, and on
+    # this run its Davidson stops in an EXCITED state of that local problem (-1.27788); the loop here starts from the
+    # diagonal and finds the lowest one (-1.60801).  The first bond is not truncated, so nothing later depends on it:
+    # every other site energy must agree to 1e-7 (they do to 4e-14).
+    first = (0, 0)
+    assert dm.energies[first] <= fx.ref_energy[first] + 1e-7
+    worst = max(abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items() if k != first)
     print("site energies", ["%.10f" % e for e in e0 + e1], "worst |dE| = %.2e" % worst)
     assert worst < 1e-7
-    assert abs(min(e0 + e1) - fx.final_energy) < 1e-7
+    assert abs(min(e0 + e1) - fx.final_energy) < 1e-7 and abs(min(e0 + e1) - (-5.424385376237)) < 1e-7
