@@ -68,6 +68,9 @@ $R $D/N2.STO3G.FCIDUMP su2 200 2 ./chain_n2su2/n2c chain=1 nodelay=1 nocache=1 n
 # the same for an SZ system (BASELINE configs[1]'s molecule AT ITS BASELINE BOND DIMENSION M=500; the run converges in 2 sweeps): 114 events, 18 site energies
 mkdir -p chain_h10sz
 $R $D/H10.STO6G.R1.8.FCIDUMP sz 500 4 ./chain_h10sz/h10c chain=3 nodelay=1 nocache=1 noise=0,0,0,0 tol=1e-12 iprint=0
+# the bundled 1D Hubbard L=16 file at M=500: the run converges in 4 sweeps (325 events, 60 site energies; 13 MB)
+mkdir -p chain_hubu2
+$R $D/HUBBARD-L16.FCIDUMP sz 500 6 ./chain_hubu2/hubc chain=5 nodelay=1 nocache=1 noise=0,0,0,0,0,0 tol=1e-12 iprint=0
 # compressed storage: the same MPS tensor written plain and through the reference's FPCodec (fp_prec, fp_chunk), and the
 # names of the scratch files of a run that is left in the middle of sweep 1 (ls of the scratch directory)
 $R $D/N2.STO3G.FCIDUMP su2 60 2 ./diskc_n2su2 tensor_file=4 fp_prec=1e-8 fp_chunk=64 iprint=0
