@@ -824,23 +824,22 @@ __global__ void vec_lincomb_k(VecPtrs vp, int nv, double *y, size_t n) {
     }
 }
 // partial[j * nblk + b] = sum over block b's grid-stride share of vs[j][i] * x[i]; fixed-order two-pass
+// (grid = blocks x vectors: the vectors of a Gram column are reduced side by side, not one after the other in a block)
 __global__ __launch_bounds__(256) void vec_multidot_k(VecPtrs vp, int nv, const double *x, size_t n, double *partial) {
     __shared__ double sh[256];
-    for (int j = 0; j < nv; j++) {
-        double s = 0.0;
-        for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-            s += vp.p[j][i] * x[i];
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o)
-                sh[threadIdx.x] += sh[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0)
-            partial[(size_t)j * gridDim.x + blockIdx.x] = sh[0];
+    const int j = blockIdx.y;
+    double s = 0.0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        s += vp.p[j][i] * x[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            sh[threadIdx.x] += sh[threadIdx.x + o];
         __syncthreads();
     }
+    if (threadIdx.x == 0)
+        partial[(size_t)j * gridDim.x + blockIdx.x] = sh[0];
 }
 __global__ __launch_bounds__(256) void vec_multidot_final_k(const double *partial, int nblk, double *out) {
     __shared__ double sh[256];
@@ -986,7 +985,7 @@ hipError_t launch_multidot(const double *const *vs, int nv, const double *x, siz
     for (int j = 0; j < nv; j++)
         vp.p[j] = vs[j], vp.coef[j] = 0.0;
     int nb = multidot_blocks(n);
-    hipLaunchKernelGGL(vec_multidot_k, dim3(nb), dim3(256), 0, st, vp, nv, x, n, partial);
+    hipLaunchKernelGGL(vec_multidot_k, dim3(nb, nv), dim3(256), 0, st, vp, nv, x, n, partial);
     hipLaunchKernelGGL(vec_multidot_final_k, dim3(nv), dim3(256), 0, st, partial, nb, out);
     return hipGetLastError();
 }
