@@ -134,6 +134,7 @@ struct b2x_plan {
     OWork *d_sum_work = nullptr;   // sum pass between the stages (distributive law), scratch -> scratch
     OEntry *d_sum_entries = nullptr;
     std::vector<SuperStep> steps;
+    std::vector<uint32_t> step_max_elems; // per super-step: elements of its largest psi' tile
     std::vector<StageCopy> stage_in; // input-vector operands copied into the scratch at the start of every execute
     // the short-tile class of a stage runs beside the tall one on a stream of its own (fork / join with events)
     hipStream_t aux_stream = nullptr;
@@ -368,6 +369,12 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
         if (rc == B2X_OK)
             rc = upload(&p->d_sum_entries, cp.sum_entries);
         p->steps = cp.steps;
+        for (const SuperStep &ss : cp.steps) { // largest tile of every step's reduce (launch_reduce)
+            uint32_t mx = 0;
+            for (uint32_t ti = ss.tile_begin; ti < ss.tile_end; ti++)
+                mx = std::max(mx, (uint32_t)cp.gtiles[ti].rows * (uint32_t)cp.gtiles[ti].cols);
+            p->step_max_elems.push_back(mx);
+        }
         p->scratch_elems = cp.scratch_elems, p->gslab_elems = cp.gslab_elems, p->slab_elems = cp.slab_elems;
         p->scratch_pads = cp.scratch_pads;
         for (const StageCopy &sc : cp.stage)
@@ -634,7 +641,8 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
     HIPCHK(launch_reduce(p->d_tiles, p->n_tiles, p->d_slabs, sigma, scale, st));
     for (const StageCopy &sc : p->stage_in) // (degenerate operands at the very end of the input vector; normally none)
         HIPCHK(hipMemcpyAsync(p->d_scratch + sc.dst_off, psi + sc.src_off, sc.len * sizeof(double), hipMemcpyDeviceToDevice, st));
-    for (const SuperStep &ss : p->steps) {
+    for (size_t si = 0; si < p->steps.size(); si++) {
+        const SuperStep &ss = p->steps[si];
         int rc = launch_stage(p, ss.s0_v, psi, st);
         if (rc != B2X_OK)
             return rc;
@@ -643,7 +651,8 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
                                 p->d_scratch, p->d_scratch, 16, st));
         if ((rc = launch_stage(p, ss.s1_v, psi, st)) != B2X_OK)
             return rc;
-        HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st));
+        HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st,
+                             si < p->step_max_elems.size() ? p->step_max_elems[si] : 0));
     }
     return B2X_OK;
 }
