@@ -68,6 +68,29 @@ std::vector<int> unit_cuts(int total, int max_units = kGGTileM / kGGRowUnit) {
     return cuts;
 }
 
+// The cut lists are asked for once or twice per PAIR and the dimensions repeat heavily (a few hundred distinct values per
+// plan): memoised, so that a plan of 10^5 pairs does not pay 3 x 10^5 small vector allocations.
+const std::vector<int> &unit_cuts_m(int total, int max_units = kGGTileM / kGGRowUnit) {
+    static thread_local std::unordered_map<uint64_t, std::vector<int>> memo;
+    if (memo.size() > (1u << 16))
+        memo.clear();
+    const uint64_t key = ((uint64_t)(uint32_t)total << 16) | (uint64_t)(uint32_t)max_units;
+    auto it = memo.find(key);
+    if (it == memo.end())
+        it = memo.emplace(key, unit_cuts(total, max_units)).first;
+    return it->second;
+}
+const std::vector<int> &wave_cuts_m(int total, int tile) {
+    static thread_local std::unordered_map<uint64_t, std::vector<int>> memo;
+    if (memo.size() > (1u << 16))
+        memo.clear();
+    const uint64_t key = ((uint64_t)(uint32_t)total << 16) | (uint64_t)(uint32_t)tile;
+    auto it = memo.find(key);
+    if (it == memo.end())
+        it = memo.emplace(key, wave_cuts(total, tile)).first;
+    return it->second;
+}
+
 // Sort the output windows and merge overlapping ones into disjoint components (sectors of the output vector with a
 // common leading dimension).  `fallback` is set when the windows cannot be laid on a common grid.
 std::vector<Component> build_components(std::vector<Window> &win, bool &fallback, std::string &reason) {
@@ -437,7 +460,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     const b2x_pair &p = pairs[win[wi].pair];
                     const double w = (double)p.m0 * p.n0 * p.k0 + (double)p.m1 * p.n1 * p.k1;
                     for (int rows : {p.m1, p.k1}) {
-                        const std::vector<int> rc = unit_cuts(rows);
+                        const std::vector<int> &rc = unit_cuts_m(rows);
                         for (size_t a = 0; a + 1 < rc.size(); a++) {
                             const int fr = ceil_div(rc[a + 1] - rc[a], kGGRowUnit);
                             const double ws = 0.5 * w * (rc[a + 1] - rc[a]) / rows;
@@ -469,8 +492,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         out.short_narrow = use_narrow;
         const int short_rows = (use_narrow ? kGGNarrowFrags : short_frags) * kGGRowUnit;
         static const int max_units_env = getenv("B2X_MAX_UNITS") ? atoi(getenv("B2X_MAX_UNITS")) : kGGTileM / kGGRowUnit; // (probe)
-        auto row_cuts = [&](int total) {
-            return use_narrow && total <= kGGShortFrags * kGGRowUnit ? unit_cuts(total, kGGNarrowFrags) : unit_cuts(total, max_units_env);
+        auto row_cuts = [&](int total) -> const std::vector<int> & {
+            return use_narrow && total <= kGGShortFrags * kGGRowUnit ? unit_cuts_m(total, kGGNarrowFrags) : unit_cuts_m(total, max_units_env);
         };
         auto col_tile = [&](int rows) { return use_narrow && rows <= short_rows ? kGGNarrowN : TN; };
         // effective pairs of this path: an operator pre-sum (below) replaces the second operator of a merged pair by a
@@ -535,10 +558,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 if (!pw.owner)
                     continue;
                 if (pw.flip) { // W'(m1 x k0) = op(Z)(m1 x k1) . X(k1 x k0)
-                    std::vector<int> rc = row_cuts(p.m1);
+                    const std::vector<int> &rc = row_cuts(p.m1);
                     const BGroup bg = s0_group(((uint64_t)1 << 63) | p.x_off, rc.size() - 1);
                     for (size_t a = 0; a + 1 < rc.size(); a++) {
-                        const std::vector<int> cc = wave_cuts(p.k0, col_tile(rc[a + 1] - rc[a]));
+                        const std::vector<int> &cc = wave_cuts_m(p.k0, col_tile(rc[a + 1] - rc[a]));
                         for (size_t b = 0; b + 1 < cc.size(); b++) {
                             s0_push_key(bg, a, b);
                             GSeg g{};
@@ -561,10 +584,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     }
                     continue;
                 }
-                std::vector<int> rc = row_cuts(p.k1);
+                const std::vector<int> &rc = row_cuts(p.k1);
                 const BGroup bg = s0_group(((uint64_t)ysrc[win[pw.wi].pair] << 62) | p.y_off, rc.size() - 1);
                 for (size_t a = 0; a + 1 < rc.size(); a++) {
-                    const std::vector<int> cc = wave_cuts(p.n0, col_tile(rc[a + 1] - rc[a]));
+                    const std::vector<int> &cc = wave_cuts_m(p.n0, col_tile(rc[a + 1] - rc[a]));
                     for (size_t b = 0; b + 1 < cc.size(); b++) {
                         s0_push_key(bg, a, b);
                         GSeg g{};
@@ -614,7 +637,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 bounds.erase(std::unique(bounds.begin(), bounds.end()), bounds.end());
                 std::vector<int> rc;
                 for (size_t bi = 0; bi + 1 < bounds.size(); bi++) {
-                    std::vector<int> sub = row_cuts(bounds[bi + 1] - bounds[bi]);
+                    const std::vector<int> &sub = row_cuts(bounds[bi + 1] - bounds[bi]);
                     for (size_t k = 0; k + 1 < sub.size(); k++)
                         rc.push_back(bounds[bi] + sub[k]);
                 }
@@ -1000,26 +1023,32 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         if (allow_flip) {
             // order of each pair: stage-0 cost amortised over the pairs that would share the product + its own stage 1
             auto group_sizes = [&](bool fl) { // size of every candidate's sharing group: hash table on the 7-word key
-                struct Slot {
-                    uint64_t key[7];
-                    uint32_t count, used;
+                struct Slot { // 16 bytes: the table of a 10^5-pair plan stays in the last-level cache
+                    uint64_t h;
+                    uint32_t count, first; // first = candidate that opened the slot (+1; 0 = empty)
                 };
                 size_t cap = 64;
                 while (cap < 2 * cand.size())
                     cap <<= 1;
-                std::vector<Slot> tab(cap);
+                std::vector<Slot> tab(cap, Slot{0, 0, 0});
                 std::vector<uint32_t> slot_of(cand.size());
                 for (size_t q = 0; q < cand.size(); q++) {
-                    uint64_t key[7];
+                    uint64_t key[7], k2[7];
                     make_key(ep[win[cand[q].wi].pair], fl, key);
                     uint64_t h = 0x9E3779B97F4A7C15ull;
                     for (int k = 0; k < 7; k++)
                         h = (h ^ key[k]) * 0xBF58476D1CE4E5B9ull, h ^= h >> 29;
                     size_t i = (size_t)h & (cap - 1);
-                    while (tab[i].used && !std::equal(key, key + 7, tab[i].key))
+                    while (tab[i].first != 0) {
+                        if (tab[i].h == h) { // confirm on the full key of the slot's first member
+                            make_key(ep[win[cand[tab[i].first - 1].wi].pair], fl, k2);
+                            if (std::equal(key, key + 7, k2))
+                                break;
+                        }
                         i = (i + 1) & (cap - 1);
-                    if (!tab[i].used)
-                        tab[i].used = 1, std::copy(key, key + 7, tab[i].key);
+                    }
+                    if (tab[i].first == 0)
+                        tab[i].h = h, tab[i].first = (uint32_t)q + 1;
                     tab[i].count++, slot_of[q] = (uint32_t)i;
                 }
                 std::vector<uint32_t> sz(cand.size());
