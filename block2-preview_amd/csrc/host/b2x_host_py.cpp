@@ -348,7 +348,8 @@ PYBIND11_MODULE(b2x_host, m) {
     m.def("davidson_device",
           [](uintptr_t plan, uintptr_t diag_dev, py::object ket_dev, size_t n, double conv_thrd, int max_iter, int soft_max_iter,
              int deflation_min_size, int deflation_max_size, bool iprint, double rel_conv_thrd, DavidsonTypes davidson_type,
-             double shift, std::vector<uintptr_t> ors, std::vector<double> proj_weights, py::object comm) -> py::object {
+             double shift, std::vector<uintptr_t> ors, std::vector<double> proj_weights, py::object comm,
+             std::vector<uintptr_t> more_plans) -> py::object {
               b2x_plan *p = (b2x_plan *)plan;
               DeviceComm dc;
               const bool para = !comm.is_none();
@@ -358,8 +359,10 @@ PYBIND11_MODULE(b2x_host, m) {
                   dc.rank = t[1].cast<int>(), dc.size = t[2].cast<int>(), dc.root = t[3].cast<int>();
               }
               size_t slen = n;
-              auto f = [p, para, dc, slen](const double *b, double *s) {
+              auto f = [p, para, dc, slen, more_plans](const double *b, double *s) {
                   check(b2x_plan_execute(p, b, s, 1.0, 1, nullptr));
+                  for (uintptr_t q : more_plans) // H = sum of several plans (sum-MPO ranks held by one process)
+                      check(b2x_plan_execute((b2x_plan *)q, b, s, 1.0, 1, nullptr));
                   if (para) // ParallelTensorFunctions::operator() (parallel_tensor_functions.hpp:51-55)
                       check(b2x_allreduce_sum(dc.comm, s, slen, nullptr));
               };
@@ -386,7 +389,7 @@ PYBIND11_MODULE(b2x_host, m) {
           py::arg("deflation_max_size") = 50, py::arg("iprint") = false, py::arg("rel_conv_thrd") = 0.0,
           py::arg("davidson_type") = DavidsonTypes::Normal, py::arg("shift") = 0.0,
           py::arg("ors") = std::vector<uintptr_t>(), py::arg("proj_weights") = std::vector<double>(),
-          py::arg("comm") = py::none());
+          py::arg("comm") = py::none(), py::arg("more_plans") = std::vector<uintptr_t>());
     // Threading.seq_type + the process-wide instance (pybind_core.hpp:1726-1731, Global.threading)
     py::class_<Threading, std::shared_ptr<Threading>>(m, "Threading")
         .def(py::init<>())

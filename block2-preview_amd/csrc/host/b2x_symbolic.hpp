@@ -465,7 +465,10 @@ template <typename S> struct OperatorFunctions {
         int ik = (int)(std::lower_bound(ci.quanta.begin() + ci.n[conj], ci.quanta.begin() + ci.n[conj + 1], abdq) -
                        ci.quanta.begin());
         if (ik >= ci.n[conj + 1] || ci.quanta[ik] != abdq)
-            throw std::runtime_error("tensor_product: sub-label not in the connection info");
+            throw std::runtime_error("tensor_product: sub-label not in the connection info (conj " + std::to_string((int)conj) +
+                                     ", a.dq " + std::to_string(adq.data) + ", b.dq " + std::to_string(bdq.data) + ", c.dq " +
+                                     std::to_string(cdq.data) + ", sub-labels of this conj: " +
+                                     std::to_string(ci.n[conj + 1] - ci.n[conj]) + ")");
         int ixa = (int)ci.idx[ik], ixb = ik == ci.n[4] - 1 ? ci.nc : (int)ci.idx[ik + 1];
         for (int il = ixa; il < ixb; il++)
             seq->tensor_product(a[(int)ci.ia[il]], conj & 1, b[(int)ci.ib[il]], (conj & 2) >> 1, c[(int)ci.ic[il]],

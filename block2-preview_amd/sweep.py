@@ -225,8 +225,9 @@ class DMRG:
             t = self._transform(self.fx.next("lntr", "rntr", "lint", "rint")[1], t)
         return t
 
-    def _eigs(self, d):
-        """H_eff of the site from the two enlarged blocks (all in HBM): plan + diagonal, then Davidson on the device"""
+    def _eff_ham(self, d):
+        """H_eff of the site from the two enlarged blocks (all in HBM): the plan and THIS Hamiltonian's diagonal on the
+        device.  (sum-MPO: one such part per rank; the parts are solved together, _solve)"""
         t0 = time.perf_counter()
         al = int(d["arena.len"][0])
         dd = dict(d)
@@ -256,7 +257,22 @@ class DMRG:
         diag = capi.DeviceBuffer(n)
         capi.diag_build(arena, dterms, diag.ptr, n, True)
         self.tm.add("eff_ham.device", t0)
+        return {"plan": plan, "arena": arena, "arena_t": arena_t, "diag": diag, "kinfo": kinfo, "n": n,
+                "const_e": float(d["const_e"][0]), "n_pairs": len(pairs)}
+
+    def _solve(self, parts):
+        """Davidson on the device over H = sum of the parts' plans (one part: the serial case; several: the sum-MPO
+        Hamiltonian H = sum_r H_r with every H_r psi accumulated into the same sigma — on separate GPUs that sum is the
+        all-reduce of ParallelTensorFunctions::operator()).  The diagonals of the parts are summed likewise."""
+        import ctypes as C
+
         t0 = time.perf_counter()
+        p0 = parts[0]
+        n, diag, plan = p0["n"], p0["diag"], p0["plan"]
+        for q in parts[1:]:
+            assert q["n"] == n
+            capi.check(capi.lib().b2x_vec_axpy(C.c_double(1.0), C.c_void_p(q["diag"].ptr), C.c_void_p(diag.ptr), C.c_size_t(n), None))
+        more = [q["plan"]._h.value for q in parts[1:]]
         # Initial guess.  block2 starts Davidson from the wavefunction of the previous site; this loop carries no
         # wavefunction from site to site, so it starts from the low end of the diagonal (the usual Davidson guess) and
         # checks the answer against the variational bound E0 <= min(diag): a Ritz pair with a tiny residual above that
@@ -266,7 +282,7 @@ class DMRG:
         ket = capi.DeviceBuffer(n, guess)
         ndav = 0
         for attempt in range(4):
-            e, nd = self.host.davidson_device(plan._h.value, diag.ptr, ket.ptr, n, self.conv_thrd, 5000)
+            e, nd = self.host.davidson_device(plan._h.value, diag.ptr, ket.ptr, n, self.conv_thrd, 5000, more_plans=more)
             ndav += nd
             if e <= dg.min() + 1e-9:
                 break
@@ -277,15 +293,22 @@ class DMRG:
         self.tm.add("eigs", t0)
         if os.environ.get("B2X_SWEEP_DEBUG"):  # residual of the returned pair, and the diagonal as the kernels built it
             sig = capi.DeviceBuffer(n)
-            plan.execute_device(ket.ptr, sig.ptr, 1.0)
+            for q in parts:
+                q["plan"].execute_device(ket.ptr, sig.ptr, 1.0)
             capi.device_sync()
-            hs, dg = sig.download(), diag.download()
+            hs = sig.download()
             rq = float(psi @ hs) / float(psi @ psi)
-            print("   [debug] n=%d pairs=%d ndav=%d e=%.10f rayleigh=%.10f |r|=%.2e |psi|=%.6f diag[min,max]=%.3f,%.3f" % (
-                n, len(pairs), ndav, e, rq, np.linalg.norm(hs - rq * psi), np.linalg.norm(psi), dg.min(), dg.max()), flush=True)
+            print("   [debug] n=%d parts=%d ndav=%d e=%.10f rayleigh=%.10f |r|=%.2e |psi|=%.6f diag[min,max]=%.3f,%.3f" % (
+                n, len(parts), ndav, e, rq, np.linalg.norm(hs - rq * psi), np.linalg.norm(psi), dg.min(), dg.max()), flush=True)
             sig.close()
-        plan.close(), arena.close(), arena_t.close(), diag.close(), ket.close()
-        return e + float(d["const_e"][0]), ndav, psi, kinfo, len(pairs)
+        const_e = sum(q["const_e"] for q in parts)
+        for q in parts:
+            q["plan"].close(), q["arena"].close(), q["arena_t"].close(), q["diag"].close()
+        ket.close()
+        return e + const_e, ndav, psi, p0["kinfo"], sum(q["n_pairs"] for q in parts)
+
+    def _eigs(self, d):
+        return self._solve([self._eff_ham(d)])
 
     def _split(self, d, right):
         """new MPS tensor = the dominant eigenvectors of the density matrix of psi (DensityMatrix decomposition,
@@ -356,49 +379,101 @@ class DMRG:
         out = []
         for i in sites:
             t_site = time.perf_counter()
-            if forward:
-                if i > 0:  # move_to(i): rotate the enlarged left block of the previous site with the new MPS tensor
-                    _, d = fx.next("lasg", "lblk")   # (the reference re-contracts it; it is still in HBM here)
-                    _, d = fx.next("lrot")
-                    a = self._split(d, False)
-                    self.L[i] = self._rotate_and_transform(d, self.EL, a)
-                if self.EL is not None:
-                    self.EL.close()
-                if i == 0:
-                    self.EL = self._assign(fx.next("lasg")[1])
-                else:
-                    self.EL = self._block(fx.next("lblk")[1], self.L[i])
-                if self.ER is not None:
-                    self.ER.close()
-                if i == n - 2:
-                    self.ER = self._assign(fx.next("rasg")[1])
-                else:
-                    self.ER = self._block(fx.next("rblk")[1], self.R[i + 2])
-            else:
-                if i < n - 2:  # move_to(i): rotate the enlarged right block of the previous site
-                    _, d = fx.next("rasg", "rblk")
-                    _, d = fx.next("rrot")
-                    a = self._split(d, True)
-                    if i + 2 in self.R:
-                        self.R[i + 2].close()
-                    self.R[i + 2] = self._rotate_and_transform(d, self.ER, a)
-                if self.ER is not None:
-                    self.ER.close()
-                if i == n - 2:
-                    self.ER = self._assign(fx.next("rasg")[1])
-                else:
-                    self.ER = self._block(fx.next("rblk")[1], self.R[i + 2])
-                if self.EL is not None:
-                    self.EL.close()
-                if i == 0:
-                    self.EL = self._assign(fx.next("lasg")[1])
-                else:
-                    self.EL = self._block(fx.next("lblk")[1], self.L[i])
-            _, d = fx.next("eham")
-            assert (int(d["chain.meta"][0]), int(d["chain.meta"][1])) == (isw, i)
+            self._move_to(i, forward)
+            d = self._eham_event(isw, i)
             e, ndav, psi, kinfo, n_pairs = self._eigs(d)
-            self.psi = (psi, kinfo)
-            self.energies[(isw, i)], self.ndav[(isw, i)] = e, ndav
+            self._finish_site(isw, i, e, ndav, psi, kinfo)
             out.append(e)
             self.tm.add("site_total", t_site)
+        return out
+
+    def _eham_event(self, isw, i):
+        _, d = self.fx.next("eham")
+        assert (int(d["chain.meta"][0]), int(d["chain.meta"][1])) == (isw, i)
+        return d
+
+    def _finish_site(self, isw, i, e, ndav, psi, kinfo):
+        self.psi = (psi, kinfo)
+        self.energies[(isw, i)], self.ndav[(isw, i)] = e, ndav
+
+    def _move_to(self, i, forward):
+        """MovingEnvironment::move_to(i) + the two blockings of the site: the enlarged left / right blocks of site i in HBM"""
+        fx, n = self.fx, self.n_sites
+        if forward:
+            if i > 0:  # move_to(i): rotate the enlarged left block of the previous site with the new MPS tensor
+                _, d = fx.next("lasg", "lblk")   # (the reference re-contracts it; it is still in HBM here)
+                _, d = fx.next("lrot")
+                a = self._split(d, False)
+                self.L[i] = self._rotate_and_transform(d, self.EL, a)
+            if self.EL is not None:
+                self.EL.close()
+            if i == 0:
+                self.EL = self._assign(fx.next("lasg")[1])
+            else:
+                self.EL = self._block(fx.next("lblk")[1], self.L[i])
+            if self.ER is not None:
+                self.ER.close()
+            if i == n - 2:
+                self.ER = self._assign(fx.next("rasg")[1])
+            else:
+                self.ER = self._block(fx.next("rblk")[1], self.R[i + 2])
+        else:
+            if i < n - 2:  # move_to(i): rotate the enlarged right block of the previous site
+                _, d = fx.next("rasg", "rblk")
+                _, d = fx.next("rrot")
+                a = self._split(d, True)
+                if i + 2 in self.R:
+                    self.R[i + 2].close()
+                self.R[i + 2] = self._rotate_and_transform(d, self.ER, a)
+            if self.ER is not None:
+                self.ER.close()
+            if i == n - 2:
+                self.ER = self._assign(fx.next("rasg")[1])
+            else:
+                self.ER = self._block(fx.next("rblk")[1], self.R[i + 2])
+            if self.EL is not None:
+                self.EL.close()
+            if i == 0:
+                self.EL = self._assign(fx.next("lasg")[1])
+            else:
+                self.EL = self._block(fx.next("lblk")[1], self.L[i])
+
+
+class SumMPODMRG:
+    """The sum-MPO calculation H = sum_r H_r (ParallelRuleSimple partition of the integrals, one MPO / set of environments /
+    plan per rank, src/dmrg/parallel_simple.hpp:56-99, src/core/parallel_tensor_functions.hpp:51-55) carried through whole
+    sweeps in ONE process: every rank's environments are moved with that rank's events, every site is solved ONCE over the
+    sum of the ranks' plans (on one GPU per rank that sum is the all-reduce of sigma; here the plans accumulate into the same
+    device vector), and every rank rotates its blocks with the same new MPS tensor.  `fixtures` = the per-rank event
+    chains of one reference run under mpirun (oracle/ref_dump.cpp para=ij chain=...).
+    NOT YET EXERCISED end to end: the generator records the 2-rank chains, but the parallel MPO's blocking expressions contain
+    operator sums with transposed members whose products the reference forms under ONE sub-label; the symbolic walk of the
+    host mirror looks the expanded member products up one by one and does not find them.  The
+    single-part path of _solve is what every serial chain test runs; the several-plan Davidson is tested in
+    tests/test_host_gpu.py::test_davidson_over_a_sum_of_plans."""
+
+    def __init__(self, fixtures, sym, **kw):
+        self.ranks = [DMRG(fx, sym, **kw) for fx in fixtures]
+        self.energies = {}
+
+    def init_environments(self):
+        out = [r.init_environments() for r in self.ranks]
+        self.n_sites = self.ranks[0].n_sites
+        assert all(r.n_sites == self.n_sites for r in self.ranks)
+        return out[0]
+
+    def sweep(self, isw, forward):
+        n = self.n_sites
+        sites = range(0, n - 1) if forward else range(n - 2, -1, -1)
+        out = []
+        for i in sites:
+            parts = []
+            for r in self.ranks:
+                r._move_to(i, forward)
+                parts.append(r._eff_ham(r._eham_event(isw, i)))
+            e, ndav, psi, kinfo, _ = self.ranks[0]._solve(parts)
+            for r in self.ranks:
+                r._finish_site(isw, i, e, ndav, psi, kinfo)
+            self.energies[(isw, i)] = e
+            out.append(e)
         return out

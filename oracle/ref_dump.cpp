@@ -258,37 +258,39 @@ template <typename S> struct CapTF : TensorFunctions<S, double> {
 // work into a BatchGEMMSeq in SeqTypes::Auto mode (seq->rotate, :202-204) and writes that pair list as a plan file:
 //   psi   := the operator blocks of a  (stage-0 A operands),   arena := the MPS tensor(s) (bra / ket),
 //   sigma := the operator blocks of c  (stage-1 outputs), sigma_ref = what the reference computed.
-template <typename S> struct RotTF : TensorFunctions<S, double> {
+// Base = TensorFunctions (serial) or ParallelTensorFunctions (sum-MPO run under mpirun: every rank records ITS events)
+template <typename S, typename Base = TensorFunctions<S, double>> struct RotTFT : Base {
+    using Base::opf;
     typedef double FL;
     DMRG<S, FL, FL> *dmrg = nullptr;
     MovingEnvironment<S, FL, FL> *me = nullptr; // (chain mode: the initial environments are built before a DMRG exists)
     const DumpSpec *spec = nullptr;
     mutable vector<string> *log = nullptr;
-    RotTF(const shared_ptr<OperatorFunctions<S, FL>> &opf) : TensorFunctions<S, FL>(opf) {}
+    template <typename... Args> RotTFT(Args &&...args) : Base(std::forward<Args>(args)...) {}
     bool in_chain() const { return spec != nullptr && spec->lite() && (dmrg == nullptr || dmrg->isweep <= spec->chain); }
     int cur_sweep() const { return dmrg == nullptr ? -1 : dmrg->isweep; }
     int cur_center() const { return dmrg != nullptr ? dmrg->me->center : (me != nullptr ? me->center : -1); }
     void left_rotate(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<SparseMatrix<S, FL>> &mpst_bra,
                      const shared_ptr<SparseMatrix<S, FL>> &mpst_ket, shared_ptr<OperatorTensor<S, FL>> &c) const override {
-        TensorFunctions<S, FL>::left_rotate(a, mpst_bra, mpst_ket, c);
+        Base::left_rotate(a, mpst_bra, mpst_ket, c);
         maybe_capture(a, mpst_bra, mpst_ket, c, false);
     }
     void right_rotate(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<SparseMatrix<S, FL>> &mpst_bra,
                       const shared_ptr<SparseMatrix<S, FL>> &mpst_ket, shared_ptr<OperatorTensor<S, FL>> &c) const override {
-        TensorFunctions<S, FL>::right_rotate(a, mpst_bra, mpst_ket, c);
+        Base::right_rotate(a, mpst_bra, mpst_ket, c);
         maybe_capture(a, mpst_bra, mpst_ket, c, true);
     }
     // ---- blocking: c = a (x) b for every operator of the enlarged block (tensor_functions.hpp:2842-2885, 2941-2983)
     void left_contract(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<OperatorTensor<S, FL>> &b,
                        shared_ptr<OperatorTensor<S, FL>> &c, const shared_ptr<Symbolic<S>> &cexprs = nullptr,
                        OpNamesSet delayed = OpNamesSet()) const override {
-        TensorFunctions<S, FL>::left_contract(a, b, c, cexprs, delayed);
+        Base::left_contract(a, b, c, cexprs, delayed);
         capture_blocking(a, b, c, cexprs, delayed, false);
     }
     void right_contract(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<OperatorTensor<S, FL>> &b,
                         shared_ptr<OperatorTensor<S, FL>> &c, const shared_ptr<Symbolic<S>> &cexprs = nullptr,
                         OpNamesSet delayed = OpNamesSet()) const override {
-        TensorFunctions<S, FL>::right_contract(a, b, c, cexprs, delayed);
+        Base::right_contract(a, b, c, cexprs, delayed);
         capture_blocking(a, b, c, cexprs, delayed, true);
     }
     // NC -> CN switch of the conventional MPO near the middle site: new (complementary) operators are linear combinations
@@ -310,9 +312,12 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
                 off.push_back(p != nullptr && T.resolve(p, o) ? (int64_t)o : -1);
             }
             for (size_t k = 0; k < names->data.size(); k++) {
-                if (exprs->data[k]->get_type() == OpTypes::Zero)
+                shared_ptr<OpExpr<S>> e0 = exprs->data[k];
+                if (e0->get_type() == OpTypes::ExprRef) // sum-MPO: the rank's local expression
+                    e0 = dynamic_pointer_cast<OpExprRef<S>>(e0)->op;
+                if (e0->get_type() == OpTypes::Zero)
                     continue;
-                auto expr = exprs->data[k] * (1.0 / dynamic_pointer_cast<OpElement<S, FL>>(names->data[k])->factor);
+                auto expr = e0 * (1.0 / dynamic_pointer_cast<OpElement<S, FL>>(names->data[k])->factor);
                 if (expr->get_type() != OpTypes::Sum)
                     continue;
                 nop.push_back(EhamDump<S>::find_op(a, order, abs_value(names->data[k])));
@@ -327,7 +332,7 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
             ed.af.i64("term.op", top), ed.af.f64("term.factor", tf), ed.af.i64("term.conj", tcj);
             ed.af.u64("meta", vector<uint64_t>{(uint64_t)(cur_sweep() + 1), (uint64_t)cur_center(), (uint64_t)right, T.tot});
         }
-        TensorFunctions<S, FL>::numerical_transform(a, names, exprs);
+        Base::numerical_transform(a, names, exprs);
     }
     // intermediates of the NEXT blocking, formed right after a rotation (moving_environment.hpp:415, 643): operator sums
     // TEMP = sum_k factor_k * op_k (or its transpose) of the rotated block (TensorFunctions::intermediates,
@@ -337,9 +342,12 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
         vector<shared_ptr<OpSumProd<S, FL>>> made;
         if (in_chain()) { // which sums the call below creates (same selection as the reference's loop)
             auto seen = a->ops;
-            for (size_t i = 0; i < exprs->data.size(); i++)
-                if (exprs->data[i] != nullptr && exprs->data[i]->get_type() == OpTypes::Sum)
-                    for (auto &x : dynamic_pointer_cast<OpSum<S, FL>>(exprs->data[i])->strings)
+            for (size_t i = 0; i < exprs->data.size(); i++) {
+                shared_ptr<OpExpr<S>> ei = exprs->data[i];
+                if (ei != nullptr && ei->get_type() == OpTypes::ExprRef) // sum-MPO: the rank's local expression
+                    ei = dynamic_pointer_cast<OpExprRef<S>>(ei)->op;
+                if (ei != nullptr && ei->get_type() == OpTypes::Sum)
+                    for (auto &x : dynamic_pointer_cast<OpSum<S, FL>>(ei)->strings)
                         if (x->get_type() == OpTypes::SumProd) {
                             auto ex = dynamic_pointer_cast<OpSumProd<S, FL>>(x);
                             if ((left && ex->b == nullptr) || (!left && ex->a == nullptr) || ex->c == nullptr)
@@ -349,8 +357,9 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
                             seen[ex->c] = nullptr;
                             made.push_back(ex);
                         }
+            }
         }
-        TensorFunctions<S, FL>::intermediates(names, exprs, a, left);
+        Base::intermediates(names, exprs, a, left);
         if (!in_chain() || made.empty())
             return;
         EhamDump<S> ed(spec->next_event(left ? "lint" : "rint", cur_sweep(), cur_center()) + ".entr");
@@ -612,6 +621,10 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
             bool supported = true;
             set<const void *> seen2;
             function<void(const shared_ptr<OpExpr<S>> &)> flat = [&](const shared_ptr<OpExpr<S>> &e) {
+                if (e->get_type() == OpTypes::ExprRef) { // sum-MPO: the rank's local expression (ParallelMPO)
+                    flat(dynamic_pointer_cast<OpExprRef<S>>(e)->op);
+                    return;
+                }
                 if (e->get_type() == OpTypes::Prod) {
                     auto op = dynamic_pointer_cast<OpProduct<S, FL>>(e);
                     if (op->b == nullptr) {
@@ -835,6 +848,16 @@ template <typename S> struct RotTF : TensorFunctions<S, double> {
         opf_cap->seq->clear();
     }
 };
+template <typename S> using RotTF = RotTFT<S>;
+template <typename S, typename R>
+static void setup_rtf(const shared_ptr<R> &rtf, MovingEnvironment<S, double, double> *me, DMRG<S, double, double> *dm,
+                      const DumpSpec *spec, vector<string> *log, const shared_ptr<MPO<S, double>> &mpo,
+                      std::function<void(DMRG<S, double, double> *)> &set_dmrg) {
+    rtf->me = me, rtf->dmrg = dm, rtf->spec = spec, rtf->log = log;
+    mpo->tf = rtf; // MovingEnvironment rotates through mpo->tf (src/dmrg/moving_environment.hpp:360)
+    set_dmrg = [rtf](DMRG<S, double, double> *d) { rtf->dmrg = d; };
+}
+
 
 template <typename S> struct Dumper : CallbackKernel {
     typedef double FL;
@@ -970,6 +993,8 @@ template <typename S> struct Dumper : CallbackKernel {
                 assert(false);
         };
         auto ex = h->op->mat->data[0];
+        if (ex->get_type() == OpTypes::ExprRef) // sum-MPO: the rank's local expression (ParallelMPO)
+            ex = dynamic_pointer_cast<OpExprRef<S>>(ex)->op;
         if (ex->get_type() == OpTypes::Sum)
             for (auto &t : dynamic_pointer_cast<OpSum<S, FL>>(ex)->strings)
                 add_term(t);
@@ -1336,13 +1361,21 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     auto me = make_shared<MovingEnvironment<S, FL, FL>>(mpo, mps, mps, "DMRG");
     auto dumper = make_shared<Dumper<S>>();
     dumper->spec.prefix = prefix + rank_tag;
-    shared_ptr<RotTF<S>> rtf;
+    // the recording TensorFunctions: over the serial base, or — sum-MPO run — over ParallelTensorFunctions with the rule
+    bool rtf_installed = false;
+    std::function<void(DMRG<S, FL, FL> *)> rtf_set_dmrg = [](DMRG<S, FL, FL> *) {};
+    auto install_rtf = [&](DMRG<S, FL, FL> *dm) {
+        if (para_rule != nullptr)
+            setup_rtf<S>(make_shared<RotTFT<S, ParallelTensorFunctions<S, FL>>>(mpo->tf->opf, para_rule), me.get(), dm,
+                         &dumper->spec, &dumper->log, mpo, rtf_set_dmrg);
+        else
+            setup_rtf<S>(make_shared<RotTF<S>>(mpo->tf->opf), me.get(), dm, &dumper->spec, &dumper->log, mpo, rtf_set_dmrg);
+        rtf_installed = true;
+    };
     if (kv.count("chain")) { // every blocking / rotation from the very first one: hook in before the environments exist
         dumper->spec.chain = Parsing::to_int(kv["chain"]);
         dumper->spec.evlog = &dumper->log;
-        rtf = make_shared<RotTF<S>>(mpo->tf->opf);
-        rtf->me = me.get(), rtf->spec = &dumper->spec, rtf->log = &dumper->log;
-        mpo->tf = rtf;
+        install_rtf(nullptr);
     }
     me->init_environments(false);
     if (para_rule == nullptr && !kv.count("nodelay")) // (the reference's sum-MPO test keeps the default: no delayed contraction)
@@ -1362,8 +1395,7 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     dmrg->davidson_soft_max_iter = kv.count("dav_iter") ? Parsing::to_int(kv["dav_iter"]) : 4000;
     dumper->dmrg = dmrg.get();
     dumper->start_forward = mps->center == 0;
-    if (rtf != nullptr)
-        rtf->dmrg = dmrg.get();
+    rtf_set_dmrg(dmrg.get());
     if (kv.count("stop_after"))
         dumper->stop_after = *parse_pairs(kv["stop_after"]).begin();
     if (kv.count("dump"))
@@ -1390,13 +1422,10 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
         dumper->spec.blk_struct = parse_pairs(kv["blk_struct"]);
     if (kv.count("eblk"))
         dumper->spec.eblk = parse_pairs(kv["eblk"]);
-    if (rtf == nullptr &&
+    if (!rtf_installed &&
         (!dumper->spec.rot.empty() || !dumper->spec.rot_struct.empty() || !dumper->spec.erot.empty() ||
-         !dumper->spec.blk.empty() || !dumper->spec.blk_struct.empty() || !dumper->spec.eblk.empty())) {
-        rtf = make_shared<RotTF<S>>(mpo->tf->opf);
-        rtf->dmrg = dmrg.get(), rtf->spec = &dumper->spec, rtf->log = &dumper->log;
-        mpo->tf = rtf; // MovingEnvironment rotates through mpo->tf (src/dmrg/moving_environment.hpp:360)
-    }
+         !dumper->spec.blk.empty() || !dumper->spec.blk_struct.empty() || !dumper->spec.eblk.empty()))
+        install_rtf(dmrg.get());
     callback_() = dumper;
     double tol = kv.count("tol") ? Parsing::to_double(kv["tol"]) : 1E-8;
     Timer t;

@@ -222,3 +222,33 @@ def test_vec_precondition_is_the_reference_formula(host):
     ref[m] /= ld - aa[m]
     out = dq.download()
     assert out[5] == q[5] and np.abs(out - ref).max() <= 4e-16 * np.abs(ref).max()
+
+
+def test_davidson_over_a_sum_of_plans(host):
+    """davidson_device(plan, ..., more_plans=[...]): H = sum of several plans accumulating into one sigma (the sum-MPO
+    Hamiltonian H = sum_r H_r with the ranks' plans held by one process) gives the eigenpair of the undivided plan"""
+    from block2_preview_amd import capi
+
+    pf = read_plan(os.path.join(GOLDEN, "n2su2.sw2.site5.plan"))
+    arena = capi.Arena.from_host([pf.arena])
+    n = pf.psi_len
+    diag = capi.DeviceBuffer(n, pf.diag)
+    full = capi.Plan(arena, pf.pairs, n, n)
+    ket = capi.DeviceBuffer(n, pf.psi)
+    e_full, nd_full = host.davidson_device(full._h.value, diag.ptr, ket.ptr, n, 1e-12, 500)
+    v_full = ket.download()
+    half = len(pf.pairs) // 2
+    pa = capi.Plan(arena, pf.pairs[:half], n, n)
+    pb = capi.Plan(arena, pf.pairs[half:], n, n)
+    ket.upload(pf.psi)
+    e_sum, nd_sum = host.davidson_device(pa._h.value, diag.ptr, ket.ptr, n, 1e-12, 500, more_plans=[pb._h.value])
+    v_sum = ket.download()
+    assert abs(e_sum - e_full) < 1e-10 and abs(abs(v_sum @ v_full) - 1.0) < 1e-8
+    sa, sf = capi.DeviceBuffer(n), capi.DeviceBuffer(n)  # (half of the pairs alone is another operator)
+    pa.execute_device(ket.ptr, sa.ptr, 1.0)
+    full.execute_device(ket.ptr, sf.ptr, 1.0)
+    capi.device_sync()
+    assert np.abs(sa.download() - sf.download()).max() > 1e-3
+    sa.close(), sf.close()
+    for x in (full, pa, pb, arena, diag, ket):
+        x.close()
