@@ -550,7 +550,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 return r;
             };
             auto s0_push_key = [&](const BGroup &bg, size_t a, size_t b) {
-                s0_key.push_back(((uint64_t)bg.id << 24) | ((uint64_t)(((bg.row_tiles + a) / 4) & 0xFFF) << 12) | (uint64_t)((b / 4) & 0xFFF));
+                static const int sb = getenv("B2X_XCD_BLK") ? atoi(getenv("B2X_XCD_BLK")) : 4; // (probe: block edge)
+                s0_key.push_back(((uint64_t)bg.id << 24) | ((uint64_t)(((bg.row_tiles + a) / sb) & 0xFFF) << 12) | (uint64_t)((b / sb) & 0xFFF));
             };
             // stage 0: tiles of every W
             for (const PW &pw : cur) {
@@ -804,8 +805,9 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         out.gtiles.push_back(dt);
                         // sibling order: 4 x 4 blocks of tiles (a tile shares its A operands with the tiles of its row and
                         // its B operands with those of its column: a square block shares both)
-                        const uint32_t blk = (uint32_t)((a / 4) * ceil_div(nct_max, 4) + b / 4);
-                        const uint32_t key = (tile_sector << 20) | (blk << 4) | (uint32_t)((a % 4) * 4 + b % 4);
+                        static const int sb = getenv("B2X_XCD_BLK") ? atoi(getenv("B2X_XCD_BLK")) : 4; // (probe: block edge)
+                        const uint32_t blk = (uint32_t)((a / sb) * ceil_div(nct_max, sb) + b / sb);
+                        const uint32_t key = (tile_sector << 20) | ((blk & 0x3FFFu) << 6) | (uint32_t)((a % sb) * sb + b % sb);
                         for (int m2 = 0; m2 < made; m2++)
                             tile_of_item[tile_of_item.size() - 1 - m2] = key;
                         tile_seq++;
