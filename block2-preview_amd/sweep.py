@@ -446,7 +446,8 @@ class SumMPODMRG:
     sum of the ranks' plans (on one GPU per rank that sum is the all-reduce of sigma; here the plans accumulate into the same
     device vector), and every rank rotates its blocks with the same new MPS tensor.  `fixtures` = the per-rank event
     chains of one reference run under mpirun (oracle/ref_dump.cpp para=ij chain=...).
-    NOT YET EXERCISED end to end: the generator records the 2-rank chains, but the parallel MPO's blocking expressions contain
+    Exercised on a decomposition with a known answer (H = H + H: tests/test_sweep_gpu.py).  The chains of a real 2-rank
+    ParallelRuleSimple run do not replay yet: the generator records them, but the parallel MPO's blocking expressions contain
     operator sums with transposed members whose products the reference forms under ONE sub-label; the symbolic walk of the
     host mirror looks the expanded member products up one by one and does not find them.  The
     single-part path of _solve is what every serial chain test runs; the several-plan Davidson is tested in

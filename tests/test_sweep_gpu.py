@@ -81,3 +81,21 @@ def test_hubbard_l16_m500_four_sweeps_known_answer(gpu):
     print("worst |dE| = %.2e, %d of %d below 1e-9, E = %.12f" % (d.max(), int((d < 1e-9).sum()), len(d), min(es)))
     assert d.max() < 1.5e-7 and (d < 1e-9).sum() >= 45
     assert abs(min(es) - fx.final_energy) < 1e-9 and abs(min(es) - (-12.966716745583)) < 1e-7
+
+
+def test_sum_mpo_loop_on_two_copies_of_the_hamiltonian(gpu):
+    """sweep.SumMPODMRG (every rank's environments moved with that rank's events, each site solved over the SUM of the ranks'
+    plans, one new MPS tensor for all) on a decomposition with a known answer: H = H + H — two "ranks" that both carry the
+    serial N2 chain.  The eigenvectors are those of H, every site energy is exactly twice the reference's.  (The chains of a
+    real 2-rank ParallelRuleSimple run are recorded by the generator but do not replay yet: DESIGN.md section 8.)"""
+    from block2_preview_amd.sweep import ChainFixture, SumMPODMRG
+
+    fxs = [ChainFixture(os.path.join(GOLDEN, "chain_n2su2", "n2c")) for _ in range(2)]
+    dm = SumMPODMRG(fxs, "su2")
+    dm.init_environments()
+    e0 = dm.sweep(0, True)
+    e1 = dm.sweep(1, False)
+    assert all(fx.pos == len(fx.events) for fx in fxs)
+    worst = max(abs(dm.energies[k] - 2.0 * ref) for k, ref in fxs[0].ref_energy.items())
+    print("worst |E - 2 E_ref| = %.2e" % worst)
+    assert worst < 2e-7 and abs(e1[-1] - 2.0 * (-107.654122447525)) < 2e-7
