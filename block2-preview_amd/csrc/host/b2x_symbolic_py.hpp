@@ -368,13 +368,61 @@ template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
     };
     OperatorTensor<S> lop = load("lop", right ? site.mutable_data() : x.mutable_data());
     OperatorTensor<S> rop = load("rop", right ? x.mutable_data() : site.mutable_data());
+    std::vector<int> tmp_pos_l, tmp_pos_r; // temporary t -> its position in lop.ops / rop.ops (-1: other side)
+    size_t tmp_nl = lop.ops.size(), tmp_nr = rop.ops.size();
     size_t nc;
     const int64_t *ci = SymEH<S>::template arr<int64_t>(d, "c.info", &nc), *co = SymEH<S>::template arr<int64_t>(d, "c.off"),
                   *tb = SymEH<S>::template arr<int64_t>(d, "c.term_begin");
     const int64_t *ty = SymEH<S>::template arr<int64_t>(d, "term.type"), *cj = SymEH<S>::template arr<int64_t>(d, "term.conj"),
                   *ta = SymEH<S>::template arr<int64_t>(d, "term.a"), *tbi = SymEH<S>::template arr<int64_t>(d, "term.b");
     const double *tf = SymEH<S>::template arr<double>(d, "term.factor");
-    (void)ty;
+    // Temporaries (sum-MPO fixtures: operator sums with transposed members, no stored intermediate): tmp_t = sum_k factor_k *
+    // op_k (or its transpose) with the info of member 0, TensorFunctions::tensor_product's SumProd branch
+    // (tensor_functions.hpp:2236-2261).  They live behind x in the input vector's address space; their sums are recorded
+    // into a sequence of their own (executed BEFORE the products), and a term refers to temporary t as operator number
+    // (operators of that side) + t.
+    std::vector<double> tmpbuf;
+    auto seq_tmp = std::make_shared<BatchGEMMSeq>();
+    if (d.contains("tmp.side")) {
+        size_t nt;
+        const int64_t *tside = SymEH<S>::template arr<int64_t>(d, "tmp.side", &nt), *tbeg = SymEH<S>::template arr<int64_t>(d, "tmp.begin"),
+                      *top = SymEH<S>::template arr<int64_t>(d, "tmp.op"), *tcj = SymEH<S>::template arr<int64_t>(d, "tmp.conj");
+        const double *tfac = SymEH<S>::template arr<double>(d, "tmp.factor");
+        size_t tot = 0;
+        std::vector<size_t> toff(nt);
+        for (size_t t = 0; t < nt; t++) {
+            const OperatorTensor<S> &side = tside[t] ? lop : rop;
+            if (tbeg[t + 1] <= tbeg[t] || top[tbeg[t]] < 0 || top[tbeg[t]] >= (int64_t)side.ops.size())
+                throw std::runtime_error("symbolic_blocking: malformed temporary");
+            toff[t] = tot, tot += side.ops[top[tbeg[t]]]->info->get_total_memory();
+        }
+        tmpbuf.assign(tot + 1, 0.0);
+        OperatorFunctions<S> opf_tmp(seq_tmp);
+        const size_t nl = lop.ops.size(), nr = rop.ops.size();
+        for (size_t t = 0; t < nt; t++) {
+            OperatorTensor<S> &side = tside[t] ? lop : rop;
+            const size_t n_side = tside[t] ? nl : nr;
+            auto m = std::make_shared<SparseMatrix<S>>();
+            m->info = side.ops[top[tbeg[t]]]->info;
+            m->factor = 1.0, m->data = tmpbuf.data() + toff[t], m->total_memory = m->info->get_total_memory();
+            for (int64_t k = tbeg[t]; k < tbeg[t + 1]; k++) {
+                if (top[k] < 0 || top[k] >= (int64_t)n_side)
+                    throw std::runtime_error("symbolic_blocking: temporary refers to an unknown operator");
+                if (side.ops[top[k]]->data) // (a member without data is zero on this rank)
+                    opf_tmp.iadd(*m, *side.ops[top[k]], tfac[k], tcj[k] != 0);
+            }
+            side.ops.push_back(m); // index n_side + (number of temporaries of this side so far): the generator counts per fixture
+        }
+        // the generator numbers temporaries over BOTH sides (t = running index): re-index so that term.a / term.b find them
+        // (operators of the side + t  ->  position in the side's list)
+        std::vector<int> pos_l, pos_r;
+        for (size_t t = 0, il = nl, ir = nr; t < nt; t++)
+            if (tside[t])
+                pos_l.push_back((int)il++), pos_r.push_back(-1);
+            else
+                pos_r.push_back((int)ir++), pos_l.push_back(-1);
+        tmp_pos_l = pos_l, tmp_pos_r = pos_r, tmp_nl = nl, tmp_nr = nr;
+    }
     OperatorTensor<S> c;
     std::vector<std::vector<OpTerm>> exprs(nc);
     for (size_t i = 0; i < nc; i++) {
@@ -385,6 +433,14 @@ template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
         for (int64_t k = tb[i]; k < tb[i + 1]; k++) {
             OpTerm t;
             t.factor = tf[k], t.conj = (uint8_t)cj[k], t.a = (int)ta[k], t.b = (int)tbi[k];
+            if (ty[k] == 2) { // product with a temporary
+                if (t.a >= (int)tmp_nl && t.a - (int)tmp_nl < (int)tmp_pos_l.size() && tmp_pos_l[t.a - tmp_nl] >= 0)
+                    t.a = tmp_pos_l[t.a - tmp_nl];
+                else if (t.b >= (int)tmp_nr && t.b - (int)tmp_nr < (int)tmp_pos_r.size() && tmp_pos_r[t.b - tmp_nr] >= 0)
+                    t.b = tmp_pos_r[t.b - tmp_nr];
+                else
+                    throw std::runtime_error("symbolic_blocking: term refers to an unknown temporary");
+            }
             exprs[i].push_back(t);
         }
     }
@@ -397,6 +453,8 @@ template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
             src = 1, off = (uint64_t)(p - x.data());
         else if (p >= site.data() && p < site.data() + site.size())
             src = 0, off = (uint64_t)(p - site.data());
+        else if (!tmpbuf.empty() && p >= tmpbuf.data() && p < tmpbuf.data() + tmpbuf.size())
+            src = 1, off = (uint64_t)x.size() + (uint64_t)(p - tmpbuf.data()); // temporaries: behind x in the input vector
         else
             throw std::runtime_error("symbolic_blocking: operand outside the fixture's data");
     };
@@ -407,9 +465,24 @@ template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
     }
     py::array_t<uint8_t> pa(t.size() * sizeof(b2x_outer_term));
     std::memcpy(pa.mutable_data(), t.data(), t.size() * sizeof(b2x_outer_term));
+    if (tmpbuf.empty()) {
+        if (execute)
+            seq->outer_perform({{v.mutable_data(), (size_t)v.size()}});
+        return py::make_tuple(pa, v);
+    }
+    // with temporaries: (terms, v, sum terms of the temporaries, length of the temporaries' area).  The sum terms read x /
+    // the site operators and write the area behind x: input and output vector of that pass are the SAME extended vector.
     if (execute)
-        seq->outer_perform({{v.mutable_data(), (size_t)v.size()}});
-    return py::make_tuple(pa, v);
+        throw std::runtime_error("symbolic_blocking: execute = true is not built for fixtures with temporaries");
+    std::vector<b2x_outer_term> ts = seq_tmp->outer_terms;
+    for (size_t i = 0; i < ts.size(); i++) {
+        classify(seq_tmp->oa_ptr[i], ts[i].a_src, ts[i].a_off);
+        ts[i].b_src = 2, ts[i].b_off = 0;
+        ts[i].c_off = (uint64_t)x.size() + (uint64_t)(seq_tmp->oc_ptr[i] - tmpbuf.data());
+    }
+    py::array_t<uint8_t> ps(ts.size() * sizeof(b2x_outer_term));
+    std::memcpy(ps.mutable_data(), ts.data(), ts.size() * sizeof(b2x_outer_term));
+    return py::make_tuple(pa, v, ps, (size_t)(tmpbuf.size() - 1));
 }
 
 // Numerical transform from a symbolic-level fixture (oracle/ref_dump.cpp chain mode, `.entr`): the operators of one block
@@ -440,8 +513,12 @@ template <typename S> py::array sym_transform(const py::dict &d) {
     OperatorFunctions<S> opf(seq);
     for (size_t k = 0; k < nn; k++)
         for (int64_t j = tb[k]; j < tb[k + 1]; j++) {
-            if (nop[k] < 0 || top[j] < 0 || !ops[nop[k]]->data || !ops[top[j]]->data)
-                throw std::runtime_error("symbolic_transform: operator without data");
+            if (nop[k] < 0 || top[j] < 0)
+                throw std::runtime_error("symbolic_transform: unknown operator");
+            // (an operator without data is identically zero here — in a sum-MPO run every rank holds a part of the integrals
+            // and some of its operators vanish; the reference's iadd skips them, operator_functions.hpp:135-174)
+            if (!ops[nop[k]]->data || !ops[top[j]]->data)
+                continue;
             opf.iadd(*ops[nop[k]], *ops[top[j]], tf[j], tcj[j] != 0);
         }
     std::vector<b2x_outer_term> terms = seq->outer_terms;

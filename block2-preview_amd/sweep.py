@@ -160,12 +160,26 @@ class DMRG:
         x, tmp = self._repack(blk, d[pre + ".key"], d[pre + ".off"], lens, xl)
         dd = dict(d)
         dd["x"] = np.zeros(xl)
-        terms, v = self.host.symbolic_blocking(self.sym, dd, False)
+        res = self.host.symbolic_blocking(self.sym, dd, False)
+        terms, v = res[0], res[1]
         terms = np.frombuffer(np.asarray(terms).tobytes(), OUTER_TERM_DTYPE)
         layout = {int(k): (int(o), _info(d, i)["len"]) for k, i, o in zip(d["c.key"], d["c.info"], d["c.off"])}
         out = OpTensor(len(v), layout)
         site = capi.Arena.from_host([np.ascontiguousarray(d["site"], np.float64)])
-        capi.outer_build(site, terms, x.buf.ptr, out.buf.ptr, True, xl, len(v))
+        x_len = xl
+        if len(res) == 4:
+            # operator sums with transposed members (sum-MPO MPOs): the temporaries live behind the block operators in the
+            # input vector and are formed first, by a pass that reads and writes that extended vector
+            sum_terms = np.frombuffer(np.asarray(res[2]).tobytes(), OUTER_TERM_DTYPE)
+            x_len = xl + int(res[3])
+            xe = OpTensor(x_len, {})
+            if xl:
+                capi.memcpy_d2d(xe.buf.ptr, x.buf.ptr, xl)
+            if tmp:
+                x.close()
+            x, tmp = xe, True
+            capi.outer_build(site, sum_terms, x.buf.ptr, x.buf.ptr, True, x_len, x_len)
+        capi.outer_build(site, terms, x.buf.ptr, out.buf.ptr, True, x_len, len(v))
         capi.device_sync()
         site.close()
         if tmp:
@@ -301,7 +315,8 @@ class DMRG:
             print("   [debug] n=%d parts=%d ndav=%d e=%.10f rayleigh=%.10f |r|=%.2e |psi|=%.6f diag[min,max]=%.3f,%.3f" % (
                 n, len(parts), ndav, e, rq, np.linalg.norm(hs - rq * psi), np.linalg.norm(psi), dg.min(), dg.max()), flush=True)
             sig.close()
-        const_e = sum(q["const_e"] for q in parts)
+        const_e = parts[0]["const_e"]  # (every rank's fixture carries the SAME constant: it is added once, by the root)
+        self.const_e = const_e
         for q in parts:
             q["plan"].close(), q["arena"].close(), q["arena_t"].close(), q["diag"].close()
         ket.close()
@@ -446,12 +461,8 @@ class SumMPODMRG:
     sum of the ranks' plans (on one GPU per rank that sum is the all-reduce of sigma; here the plans accumulate into the same
     device vector), and every rank rotates its blocks with the same new MPS tensor.  `fixtures` = the per-rank event
     chains of one reference run under mpirun (oracle/ref_dump.cpp para=ij chain=...).
-    Exercised on a decomposition with a known answer (H = H + H: tests/test_sweep_gpu.py).  The chains of a real 2-rank
-    ParallelRuleSimple run do not replay yet: the generator records them, but the parallel MPO's blocking expressions contain
-    operator sums with transposed members whose products the reference forms under ONE sub-label; the symbolic walk of the
-    host mirror looks the expanded member products up one by one and does not find them.  The
-    single-part path of _solve is what every serial chain test runs; the several-plan Davidson is tested in
-    tests/test_host_gpu.py::test_davidson_over_a_sum_of_plans."""
+    Tests: the 2-rank ParallelRuleSimple run of the reference (tests/golden/chain_n2su2_ij) and H = H + H
+    (tests/test_sweep_gpu.py)."""
 
     def __init__(self, fixtures, sym, **kw):
         self.ranks = [DMRG(fx, sym, **kw) for fx in fixtures]

@@ -298,7 +298,11 @@ template <typename S, typename Base = TensorFunctions<S, double>> struct RotTFT 
     // src/core/tensor_functions.hpp:2462-2517 -> OperatorFunctions::iadd, operator_functions.hpp:135-174)
     void numerical_transform(const shared_ptr<OperatorTensor<S, FL>> &a, const shared_ptr<Symbolic<S>> &names,
                              const shared_ptr<Symbolic<S>> &exprs) const override {
-        if (in_chain()) { // (written BEFORE the transform runs: the tensor's layout at this point is what a replay has)
+        // (written AFTER the transform has run: the serial reference has every new operator allocated beforehand, the
+        // sum-MPO one allocates them inside — parallel_tensor_functions.hpp:1062-1070 —, and a replay needs the layout that
+        // holds them; in chain mode no data are written, only the layout)
+        Base::numerical_transform(a, names, exprs);
+        if (in_chain()) {
             const bool right = a->lmat == nullptr;
             EhamDump<S> ed(spec->next_event(right ? "rntr" : "lntr", cur_sweep(), cur_center()) + ".entr");
             vector<const double *> ptrs;
@@ -332,7 +336,6 @@ template <typename S, typename Base = TensorFunctions<S, double>> struct RotTFT 
             ed.af.i64("term.op", top), ed.af.f64("term.factor", tf), ed.af.i64("term.conj", tcj);
             ed.af.u64("meta", vector<uint64_t>{(uint64_t)(cur_sweep() + 1), (uint64_t)cur_center(), (uint64_t)right, T.tot});
         }
-        Base::numerical_transform(a, names, exprs);
     }
     // intermediates of the NEXT blocking, formed right after a rotation (moving_environment.hpp:415, 643): operator sums
     // TEMP = sum_k factor_k * op_k (or its transpose) of the rotated block (TensorFunctions::intermediates,
@@ -616,6 +619,8 @@ template <typename S, typename Base = TensorFunctions<S, double>> struct RotTFT 
             };
             af.i64("lop.off", offs_in(lp, !right)), af.i64("rop.off", offs_in(rp, right));
             vector<int64_t> c_info, c_off, t_begin, ty, cj, ta, tb;
+            vector<int64_t> tmp_side, tmp_begin{0}, tmp_op, tmp_cj; // temporaries (operator sums with transposed members)
+            vector<double> tmp_fac;
             vector<uint64_t> c_key;
             vector<double> tf;
             bool supported = true;
@@ -637,6 +642,31 @@ template <typename S, typename Base = TensorFunctions<S, double>> struct RotTFT 
                     auto op = dynamic_pointer_cast<OpSumProd<S, FL>>(e);
                     const bool inter = op->c != nullptr && ((op->b == nullptr && rt->ops.count(op->c)) ||
                                                             (op->a == nullptr && lt->ops.count(op->c)));
+                    bool any_tr = false;
+                    for (size_t k = 0; k < op->ops.size(); k++)
+                        any_tr = any_tr || op->conjs[k];
+                    if (!inter && any_tr) {
+                        // no stored intermediate and TRANSPOSED members (the sum-MPO MPOs have them): the product is taken
+                        // under ONE sub-label of the connection info, that of (op->conj, ops[0]) — a transposed member's own
+                        // product has no entry there — so the temporary is written as what it is: tmp = sum_k factor_k *
+                        // op_k (or its transpose), info of ops[0] (tensor_functions.hpp:2236-2261), and ONE product with it.
+                        // The temporary is operator number (operators of its side) + t in the term's a / b field.
+                        const bool on_r = op->b == nullptr;
+                        const int t_idx = (int)tmp_side.size();
+                        tmp_side.push_back(on_r ? 0 : 1);
+                        for (size_t k = 0; k < op->ops.size(); k++) {
+                            auto ok = abs_value((shared_ptr<OpExpr<S>>)op->ops[k]);
+                            tmp_op.push_back(on_r ? EhamDump<S>::find_op(rt, rorder, ok) : EhamDump<S>::find_op(lt, lorder, ok));
+                            tmp_fac.push_back(op->ops[k]->factor), tmp_cj.push_back(op->conjs[k] ? 1 : 0);
+                        }
+                        tmp_begin.push_back((int64_t)tmp_op.size());
+                        ty.push_back(2), cj.push_back(op->conj), tf.push_back(op->factor);
+                        if (on_r)
+                            ta.push_back(EhamDump<S>::find_op(lt, lorder, op->a)), tb.push_back((int64_t)rorder.size() + t_idx);
+                        else
+                            ta.push_back((int64_t)lorder.size() + t_idx), tb.push_back(EhamDump<S>::find_op(rt, rorder, op->b));
+                        return;
+                    }
                     if (!inter) {
                         // no stored intermediate: the reference sums the operators into a temporary (iadd with the
                         // member's factor and transposition flag, tensor_functions.hpp:2236-2261) and takes ONE product;
@@ -681,6 +711,9 @@ template <typename S, typename Base = TensorFunctions<S, double>> struct RotTFT 
             t_begin.push_back((int64_t)ty.size());
             af.i64("c.info", c_info), af.i64("c.off", c_off), af.i64("c.term_begin", t_begin), af.u64("c.key", c_key);
             af.i64("term.type", ty), af.i64("term.conj", cj), af.f64("term.factor", tf), af.i64("term.a", ta), af.i64("term.b", tb);
+            if (!tmp_side.empty()) // (only sum-MPO runs have them: serial fixtures keep their format)
+                af.i64("tmp.side", tmp_side), af.i64("tmp.begin", tmp_begin), af.i64("tmp.op", tmp_op), af.f64("tmp.factor", tmp_fac),
+                    af.i64("tmp.conj", tmp_cj);
             af.u64("meta", vector<uint64_t>{(uint64_t)key.first, (uint64_t)key.second, (uint64_t)right, (uint64_t)supported,
                                             (uint64_t)terms.size(), X.tot, Sx.tot, V.tot});
             af.bulk("x", X.gather()), af.f64("site", Sx.gather()), af.bulk("v_ref", V.gather());

@@ -86,7 +86,7 @@ def test_hubbard_l16_m500_four_sweeps_known_answer(gpu):
 def test_sum_mpo_loop_on_two_copies_of_the_hamiltonian(gpu):
     """sweep.SumMPODMRG (every rank's environments moved with that rank's events, each site solved over the SUM of the ranks'
     plans, one new MPS tensor for all) on a decomposition with a known answer: H = H + H — two "ranks" that both carry the
-    serial N2 chain.  The eigenvectors are those of H, every site energy is exactly twice the reference's.  (The chains of a
+    serial N2 chain.  The eigenvectors are those of H, every site energy is twice the reference's electronic part plus the constant.  (The chains of a
     real 2-rank ParallelRuleSimple run are recorded by the generator but do not replay yet: DESIGN.md section 8.)"""
     from block2_preview_amd.sweep import ChainFixture, SumMPODMRG
 
@@ -96,6 +96,35 @@ def test_sum_mpo_loop_on_two_copies_of_the_hamiltonian(gpu):
     e0 = dm.sweep(0, True)
     e1 = dm.sweep(1, False)
     assert all(fx.pos == len(fx.events) for fx in fxs)
-    worst = max(abs(dm.energies[k] - 2.0 * ref) for k, ref in fxs[0].ref_energy.items())
-    print("worst |E - 2 E_ref| = %.2e" % worst)
-    assert worst < 2e-7 and abs(e1[-1] - 2.0 * (-107.654122447525)) < 2e-7
+    c = dm.ranks[0].const_e  # the constant of the Hamiltonian is added once: E = 2 (E_ref - c) + c
+    worst = max(abs(dm.energies[k] - (2.0 * ref - c)) for k, ref in fxs[0].ref_energy.items())
+    print("worst |E - (2 E_ref - c)| = %.2e" % worst)
+    assert worst < 2e-7 and abs(e1[-1] - (2.0 * (-107.654122447525) - c)) < 2e-7
+
+
+def test_sum_mpo_two_ranks_energy(gpu):
+    """The sum-MPO calculation of the reference on 2 MPI ranks (ParallelRuleSimple IJ, unit_test/mpi/test_sum_mpo_n2_sto3g.cpp
+    :209-226; the event chains of BOTH ranks in tests/golden/chain_n2su2_ij): every rank's operators are blocked, rotated and
+    contracted with that rank's events, every site is solved over H = H_0 + H_1 (the ranks' plans accumulate into one sigma:
+    what the all-reduce does across GPUs).  All 18 site energies of the reference run to 1e-7 and the final energy
+    -107.654122447525 (the reference test's answer, :224)."""
+    from block2_preview_amd.sweep import ChainFixture, DMRG, SumMPODMRG
+
+    fxs = [ChainFixture(os.path.join(GOLDEN, "chain_n2su2_ij", "n2p.r%dof2" % r)) for r in range(2)]
+    assert len(fxs[0].ref_energy) == 18 and fxs[0].ref_energy == fxs[1].ref_energy
+    dm = SumMPODMRG(fxs, "su2")
+    dm.init_environments()
+    assert dm.n_sites == 10
+    e0 = dm.sweep(0, True)
+    e1 = dm.sweep(1, False)
+    assert all(fx.pos == len(fx.events) for fx in fxs)
+    worst = max(abs(dm.energies[k] - ref) for k, ref in fxs[0].ref_energy.items())
+    print("sum-MPO site energies", ["%.10f" % e for e in e0 + e1], "worst |dE| = %.2e" % worst)
+    assert worst < 1e-7
+    assert abs(e1[-1] - (-107.654122447525)) < 1e-7
+    # one rank's Hamiltonian alone is NOT the Hamiltonian
+    one = DMRG(ChainFixture(os.path.join(GOLDEN, "chain_n2su2_ij", "n2p.r0of2")), "su2")
+    one.init_environments()
+    one._move_to(0, True)
+    e_part, _, _, _, _ = one._eigs(one._eham_event(0, 0))
+    assert abs(e_part - fxs[0].ref_energy[(0, 0)]) > 1e-2
