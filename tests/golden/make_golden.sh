@@ -71,6 +71,9 @@ $R $D/H10.STO6G.R1.8.FCIDUMP sz 500 4 ./chain_h10sz/h10c chain=3 nodelay=1 nocac
 # the 2-rank sum-MPO run (ParallelRuleSimple IJ) with the event chain of EVERY rank: n2p.r{0,1}of2.*
 mkdir -p chain_n2su2_ij
 /opt/conda/bin/mpirun -n 2 ../../oracle/_ref/ref_dump_mpi $D/N2.STO3G.FCIDUMP su2 200 2 ./chain_n2su2_ij/n2p para=ij chain=1 nocache=1 nthreads=2 noise=0,0 tol=1e-12 iprint=0
+# ... and a 4-rank run
+mkdir -p chain_n2su2_ij4
+/opt/conda/bin/mpirun -n 4 ../../oracle/_ref/ref_dump_mpi $D/N2.STO3G.FCIDUMP su2 200 2 ./chain_n2su2_ij4/n2p para=ij chain=1 nocache=1 nthreads=1 noise=0,0 tol=1e-12 iprint=0
 # the bundled 1D Hubbard L=16 file at M=500: the run converges in 4 sweeps (325 events, 60 site energies; 13 MB)
 mkdir -p chain_hubu2
 $R $D/HUBBARD-L16.FCIDUMP sz 500 6 ./chain_hubu2/hubc chain=5 nodelay=1 nocache=1 noise=0,0,0,0,0,0 tol=1e-12 iprint=0
