@@ -35,6 +35,15 @@ class ChainFixture:
     """<prefix>.ev<NNN>.<kind>.<ext> files + <prefix>.log of one reference run (ref_dump chain=<sweep> nodelay=1 nocache=1)"""
 
     def __init__(self, prefix):
+        if not os.path.exists(prefix + ".log") and os.path.exists(prefix + ".zip"):
+            # a large chain kept as one compressed archive (<name>.zip next to where <name>.log would be): unpacked once
+            import tempfile
+            import zipfile
+
+            self._tmp = tempfile.TemporaryDirectory(prefix="b2x_chain_")
+            with zipfile.ZipFile(prefix + ".zip") as z:
+                z.extractall(self._tmp.name)
+            prefix = os.path.join(self._tmp.name, os.path.basename(prefix))
         self.events = []
         for fn in sorted(glob.glob(prefix + ".ev*")):
             m = re.search(r"\.ev(\d+)\.([a-z]+)\.e[a-z]+$", fn)

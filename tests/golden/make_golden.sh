@@ -74,6 +74,10 @@ mkdir -p chain_n2su2_ij
 # ... and a 4-rank run
 mkdir -p chain_n2su2_ij4
 /opt/conda/bin/mpirun -n 4 ../../oracle/_ref/ref_dump_mpi $D/N2.STO3G.FCIDUMP su2 200 2 ./chain_n2su2_ij4/n2p para=ij chain=1 nocache=1 nthreads=1 noise=0,0 tol=1e-12 iprint=0
+# Cr2/SVP at M=30, two sweeps: 539 events, 51 MB raw -> kept as chain_cr2/cr2c.zip (sweep.ChainFixture unpacks it)
+mkdir -p chain_cr2 /tmp/b2x_cr2c
+$R $D/CR2.SVP.FCIDUMP su2 30 2 /tmp/b2x_cr2c/cr2c chain=1 nodelay=1 nocache=1 noise=0,0 tol=1e-12 iprint=0 occ=$D/CR2.SVP.OCC
+(cd /tmp/b2x_cr2c && python3 -c "import zipfile,glob,os; z=zipfile.ZipFile('cr2c.zip','w',zipfile.ZIP_DEFLATED,compresslevel=9); [z.write(f) for f in sorted(glob.glob('cr2c.ev*')+['cr2c.log'])]; z.close()") && cp /tmp/b2x_cr2c/cr2c.zip chain_cr2/
 # the bundled 1D Hubbard L=16 file at M=500: the run converges in 4 sweeps (325 events, 60 site energies; 13 MB)
 mkdir -p chain_hubu2
 $R $D/HUBBARD-L16.FCIDUMP sz 500 6 ./chain_hubu2/hubc chain=5 nodelay=1 nocache=1 noise=0,0,0,0,0,0 tol=1e-12 iprint=0

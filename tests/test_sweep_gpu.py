@@ -145,3 +145,25 @@ def test_sum_mpo_four_ranks_energy(gpu):
     worst = max(abs(dm.energies[k] - ref) for k, ref in fxs[0].ref_energy.items())
     print("4-rank sum-MPO worst |dE| = %.2e, E = %.12f" % (worst, e1[-1]))
     assert worst < 1e-7 and abs(e1[-1] - (-107.654122447525)) < 1e-7
+
+
+def test_cr2_svp_chain_m30(gpu):
+    """Cr2/SVP (the molecule of BASELINE configs[2-3]: 42 orbitals, D2h, SU2, bond dimensions from CR2.SVP.OCC) at M=30: the
+    539 events of two sweeps of one reference run (tests/golden/chain_cr2/cr2c.zip) replayed through all 82 sites.  At M=30
+    nearly every bond is truncated, and from the first truncated bond on (site 6) ties among the density-matrix weights are
+    broken differently than in the reference: the site energies before it are exact, the others agree to 5e-5 (4e-7
+    typical), and the final energy is NOT ABOVE the reference's (-2086.1190566236; here 2.7e-6 lower)."""
+    from block2_preview_amd.sweep import DMRG, ChainFixture
+
+    fx = ChainFixture(os.path.join(GOLDEN, "chain_cr2", "cr2c"))
+    assert len(fx.events) == 539 and len(fx.ref_energy) == 82
+    dm = DMRG(fx, "su2")
+    dm.init_environments()
+    assert dm.n_sites == 42
+    es = dm.sweep(0, True) + dm.sweep(1, False)
+    assert fx.pos == len(fx.events)
+    d = {k: abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items()}
+    print("Cr2 M=30: worst |dE| = %.2e, final %.10f (reference %.10f)" % (max(d.values()), min(es), fx.final_energy))
+    assert all(d[(0, i)] < 1e-9 for i in range(6))
+    assert max(d.values()) < 5e-5
+    assert min(es) <= fx.final_energy + 1e-7 and abs(min(es) - fx.final_energy) < 1e-5
