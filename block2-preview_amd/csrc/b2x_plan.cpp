@@ -1,9 +1,15 @@
 // b2x_plan.cpp — plan compiler (host).  See b2x_plan.hpp for the scheme.
 #include "b2x_plan.hpp"
 #include <algorithm>
+#include <array>
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
+#include <string>
 #include <cmath>
 #include <map>
+#include <memory_resource>
+#include <sys/mman.h>
 #include <cstring>
 #include <cstdlib>
 #include <numeric>
@@ -25,6 +31,84 @@ struct Component {
     uint32_t w_begin, w_end; // windows (sorted array) of this component
 };
 
+// Memory of the plan compiler's temporaries.  A plan of 10^5 pairs allocates (and frees) some hundred MB of short-lived
+// lists per compilation; through malloc every large one is a fresh mmap whose pages are faulted in one by one — a
+// quarter of the compile time (Cr2 M=250 plan 163 -> 118 ms, x16 plan 441 -> 318 ms with a retained heap).  The
+// temporaries therefore come from a per-thread bump arena that is rewound, not released, when a compilation ends
+// (2 MB-aligned anonymous mappings, MADV_HUGEPAGE where the kernel offers it; given back above kKeepBytes).
+class ScratchArena : public std::pmr::memory_resource {
+    struct Chunk {
+        char *p;
+        size_t cap;
+    };
+    std::vector<Chunk> chunks;
+    size_t cur = 0, off = 0;
+    static constexpr size_t kChunk = (size_t)64 << 20, kKeepBytes = (size_t)1 << 30;
+    void *do_allocate(size_t bytes, size_t align) override {
+        for (;; cur++, off = 0) {
+            if (cur == chunks.size()) {
+                const size_t cap = (std::max(bytes + align, kChunk) + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+                void *m = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+                if (m == MAP_FAILED)
+                    throw std::bad_alloc();
+                (void)madvise(m, cap, MADV_HUGEPAGE);
+                chunks.push_back(Chunk{(char *)m, cap});
+            }
+            const size_t o = (off + align - 1) & ~(align - 1);
+            if (o + bytes <= chunks[cur].cap) {
+                off = o + bytes;
+                return chunks[cur].p + o;
+            }
+        }
+    }
+    void do_deallocate(void *, size_t, size_t) override {}
+    bool do_is_equal(const std::pmr::memory_resource &o) const noexcept override { return this == &o; }
+
+  public:
+    size_t capacity() const {
+        size_t t = 0;
+        for (const Chunk &c : chunks)
+            t += c.cap;
+        return t;
+    }
+    void rewind() {
+        if (capacity() > kKeepBytes) {
+            for (const Chunk &c : chunks)
+                munmap(c.p, c.cap);
+            chunks.clear();
+        }
+        cur = 0, off = 0;
+    }
+    ~ScratchArena() override {
+        for (const Chunk &c : chunks)
+            munmap(c.p, c.cap);
+    }
+};
+struct ArenaScope { // rewinds the arena when the compilation ends, however it ends
+    ScratchArena &a;
+    ~ArenaScope() { a.rewind(); }
+};
+template <class T> using tvec = std::pmr::vector<T>;
+
+// (development aid, B2X_PLAN_DEBUG=1) wall time of the phases of compile_plan, on stderr
+struct PhaseClock {
+    bool on = getenv("B2X_PLAN_DEBUG") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    std::map<std::string, double> acc;
+    void lap(const char *name) {
+        if (!on)
+            return;
+        const auto n = std::chrono::steady_clock::now();
+        acc[name] += std::chrono::duration<double, std::milli>(n - t).count();
+        t = n;
+    }
+    void report() {
+        if (!on)
+            return;
+        for (auto &kv : acc)
+            fprintf(stderr, "[b2x plan] phase %-22s %8.2f ms\n", kv.first.c_str(), kv.second);
+    }
+};
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 
@@ -200,8 +284,12 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     out = CompiledPlan();
     b2x_plan_stats &st = out.stats;
     st.n_pairs = n_pairs, st.psi_len = psi_len, st.sigma_len = sigma_len;
+    PhaseClock pc;
+    static thread_local ScratchArena mem_arena;
+    ScratchArena *const mem = &mem_arena;
+    ArenaScope mem_scope{mem_arena};
     // ---- validation + statistics -------------------------------------------------------------
-    std::vector<std::pair<uint64_t, uint64_t>> opext;
+    tvec<std::pair<uint64_t, uint64_t>> opext(mem);
     opext.reserve(2 * n_pairs);
     for (size_t i = 0; i < n_pairs; i++) {
         const b2x_pair &p = pairs[i];
@@ -230,6 +318,20 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         opext.emplace_back(p.y_off, ey);
         opext.emplace_back(p.z_off, ez);
     }
+    { // (an operator block is named by many pairs: distinct (offset, extent) first — a hash set —, then the sort)
+        size_t cap = 1024;
+        while (cap < 2 * opext.size())
+            cap <<= 1;
+        tvec<std::pair<uint64_t, uint64_t>> set(cap, std::make_pair(~(uint64_t)0, (uint64_t)0), mem), uniq(mem);
+        for (const auto &e : opext) {
+            size_t i = (size_t)((e.first * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+            while (set[i].first != ~(uint64_t)0 && set[i] != e)
+                i = (i + 1) & (cap - 1);
+            if (set[i].first == ~(uint64_t)0)
+                set[i] = e, uniq.push_back(e);
+        }
+        opext.swap(uniq);
+    }
     std::sort(opext.begin(), opext.end());
     {
         uint64_t cur_b = 0, cur_e = 0;
@@ -244,6 +346,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     }
     if (n_pairs == 0)
         return B2X_OK;
+    pc.lap("0 validate");
     // ---- output windows -> disjoint components -----------------------------------------------
     std::vector<Window> win(n_pairs);
     for (size_t i = 0; i < n_pairs; i++)
@@ -253,6 +356,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     st.fallback = out.fallback;
     if (out.fallback)
         return B2X_OK;
+    pc.lap("1 components");
     // ---- tiles, parts, items -----------------------------------------------------------------
     struct HostTile {
         int cls;
@@ -433,6 +537,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         });
         st.n_items += cw.items.size();
     }
+    pc.lap("2 fused tiles");
     // ---- two-stage path: W = alpha X op(Y) to scratch, then psi' tiles += op(Z) W ---------------
     uint64_t gg_macs = 0;
     if (!big.empty()) {
@@ -477,6 +582,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                                   ? sf_env
                                   : (wt > 0 && w3 / wt < 0.25 && w5 / wt > 0.3 ? kGGMidFrags : kGGShortFrags);
         }
+        pc.lap("3 class estimates");
         const int short_frags = out.short_frags;
         // Short tiles of plans with narrow sectors run on ONE-WAVE workgroups of 32 columns (gg_kernel<CF, NW = 1, ...,
         // TMAX = kGGNarrowFrags>: 116 VGPRs, 8 KB of LDS, 16 independent workgroups per CU): in a 2-wave workgroup the
@@ -498,8 +604,21 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         auto col_tile = [&](int rows) { return use_narrow && rows <= short_rows ? kGGNarrowN : TN; };
         // effective pairs of this path: an operator pre-sum (below) replaces the second operator of a merged pair by a
         // block in the plan's own buffer (source 2 = scratch, whose first aux_len elements persist across executions)
-        std::vector<b2x_pair> ep(pairs, pairs + n_pairs);
-        std::vector<uint8_t> zsrc(n_pairs, 0), ysrc(n_pairs, 0);
+        // The segment list of a large plan is 10^6-10^7 records of 64 bytes: grown by doubling it is copied (and its fresh
+        // pages faulted in) three times over.  An upper estimate of its length is reserved instead (address space only;
+        // x16 Cr2 plan: compile 669 -> 594 ms): tiles of a pair's windows in both stages, plus one cut per window for
+        // the row ranges other windows of the sector split.
+        {
+            size_t est = 0;
+            for (size_t i = 0; i < n_pairs; i++) {
+                const b2x_pair &p = pairs[i];
+                const size_t ct = (size_t)ceil_div(p.n0, use_narrow ? kGGNarrowN : TN) + 1;
+                est += ((size_t)ceil_div(p.m1, kGGTileM) + 2) * ct + ((size_t)ceil_div(std::max(p.k1, p.m1), kGGTileM) + 1) * ct;
+            }
+            out.gsegs.reserve(est), out.gitems.reserve(est);
+        }
+        tvec<b2x_pair> ep(pairs, pairs + n_pairs, mem);
+        tvec<uint8_t> zsrc(n_pairs, 0, mem), ysrc(n_pairs, 0, mem);
         uint64_t aux_len = 0;
         const uint64_t budget = (uint64_t)(opt && opt->scratch_mb > 0 ? opt->scratch_mb : 16384) * (1u << 17);
         // work in component order; a super-step closes when the W scratch budget is reached
@@ -523,11 +642,12 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             bool owner; // generates the stage-0 items of its W
         };
         const bool allow_flip = !(opt && opt->keep_order == 1);
-        std::vector<PW> cur;
+        tvec<PW> cur(mem);
         uint64_t used = 0;
         auto flush = [&]() {
             if (cur.empty())
                 return;
+            pc.lap("4b super-step fill");
             SuperStep ss{};
             ss.sum_begin = (uint32_t)out.sum_work.size();
             uint64_t sum_extra = 0; // scratch taken by the sums of this step, behind its W slots
@@ -536,7 +656,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             // psi slices X_i that meet one right-operator block Y, op(Z_i) . X for the left-operator blocks that meet one
             // psi slice X — are the row blocks of ONE tall product [X_1; X_2; ...] . op(Y): its tiles of one column read the
             // same B tile, those of one row the same A rows.  key = (B operand, 4 x 4 block of tiles of that tall product).
-            std::vector<uint64_t> s0_key;
+            tvec<uint64_t> s0_key(mem);
             struct BGroup {
                 uint32_t id, row_tiles;
             };
@@ -610,16 +730,30 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     }
                 }
             }
+            pc.lap("5 stage-0 items");
             const uint32_t s1_begin = (uint32_t)out.gitems.size();
-            std::vector<uint32_t> tile_of_item; // stage-1 items in creation order -> running number of their tile
+            tvec<uint32_t> tile_of_item(mem); // stage-1 items in creation order -> running number of their tile
             uint32_t tile_seq = 0, tile_sector = 0;
             ss.tile_begin = (uint32_t)out.gtiles.size();
             // stage 1: per component, per psi' tile, the segments of this step's pairs
             uint64_t slab = 0;
             // (the step's pairs arrive in stage-0 key order: regroup them by psi' sector, plan order inside a sector)
-            std::stable_sort(cur.begin(), cur.end(), [](const PW &x, const PW &y) {
-                return x.c != y.c ? x.c < y.c : x.wi < y.wi;
-            });
+            // (components are runs of the offset-sorted window array, and a window belongs to one pair: window order IS
+            // sector order; one pass over a window-indexed table instead of a comparison sort)
+            {
+                tvec<uint32_t> at(n_pairs, ~0u, mem);
+                for (size_t k = 0; k < cur.size(); k++)
+                    at[cur[k].wi] = (uint32_t)k;
+                tvec<PW> byw(mem);
+                byw.reserve(cur.size());
+                for (size_t w = 0; w < n_pairs; w++)
+                    if (at[w] != ~0u)
+                        byw.push_back(cur[at[w]]);
+                cur.swap(byw);
+            }
+            tvec<GSeg> fsegs(mem);
+            tvec<uint32_t> ftile(mem);
+            const uint32_t per_step = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, (used >> 10) / 262144));
             size_t i = 0;
             while (i < cur.size()) {
                 size_t j = i;
@@ -654,21 +788,25 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     tbase[a + 1] = tbase[a] + (ccs[a]->size() - 1);
                     nct_max = std::max(nct_max, (int)ccs[a]->size() - 1);
                 }
-                std::vector<std::vector<GSeg>> tsegs(tbase[nrt]);
-                std::vector<double> tcost(tbase[nrt], 0.0);
+                // segments of the sector in creation order (fsegs, with their tile in ftile), then scattered tile by tile
+                // into the plan's list (a list per tile cost an allocation per tile and a second copy of every segment)
+                fsegs.clear(), ftile.clear();
+                tvec<uint32_t> tstart(tbase[nrt] + 1, 0, mem);
+                tvec<double> tcost(tbase[nrt], 0.0, mem);
+                pc.lap("6a cuts");
                 // Distributive law: pairs of this sector that multiply the SAME operator block into the SAME window
                 // (op(Z) . W_i with one Z, or W'_i . op(Y) with one Y) first sum their scaled stage-0 products,
                 // S = sum_i alpha_i W_i, in an element-wise pass between the stages, then take ONE stage-1 product.
                 // Worth it only where the saved MACs outweigh the pass at HBM speed: (g - 1)/(g + 1) x (rows of Z, or
                 // columns of op(Y)) > 64 MAC per element moved.
-                std::vector<uint64_t> merged_off(j - i, ~(uint64_t)0); // S offset of a group's first member
-                std::vector<uint8_t> merged_skip(j - i, 0);             // later members: no segment of their own
+                tvec<uint64_t> merged_off(j - i, ~(uint64_t)0, mem); // S offset of a group's first member
+                tvec<uint8_t> merged_skip(j - i, 0, mem);             // later members: no segment of their own
                 if (allow_flip && j - i > 1 && !getenv("B2X_NO_MERGE")) {
                     struct MK {
                         uint64_t k[6];
                         uint32_t q;
                     };
-                    std::vector<MK> mk(j - i);
+                    tvec<MK> mk(j - i, mem);
                     for (size_t q = i; q < j; q++) {
                         const Window &w = win[cur[q].wi];
                         const b2x_pair &p = ep[w.pair];
@@ -713,7 +851,9 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             wk.rpt = 16; // outer_build_k<16>
                             wk.entry_begin = eb, wk.entry_end = (uint32_t)out.sum_entries.size();
                             const uint32_t nseg = (uint32_t)ceil_div(scols, kOuterTileCols), nstrip = (uint32_t)ceil_div(srows, wk.rpt);
-                            const uint32_t ntile = nseg * nstrip, per = ntile >= 4096 ? 4 : (ntile >= 1024 ? 2 : 1);
+                            // tiles per work unit (one wave): more for large groups, and for steps whose W products add up to
+                            // millions of tiles (x16 Cr2 plan: 2.5 M units of 40 bytes took a third of the compile time)
+                            const uint32_t ntile = nseg * nstrip, per = std::max<uint32_t>(ntile >= 4096 ? 4 : (ntile >= 1024 ? 2 : 1), per_step);
                             for (uint32_t t0 = 0; t0 < ntile; t0 += per) {
                                 wk.t_begin = t0, wk.t_end = std::min(ntile, t0 + per);
                                 out.sum_work.push_back(wk);
@@ -722,6 +862,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         a = b;
                     }
                 }
+                pc.lap("6b merge groups");
                 for (size_t q = i; q < j; q++) {
                     if (merged_skip[q - i])
                         continue;
@@ -761,18 +902,28 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                             g.mr = rb - ra, g.nc = cb - ca;
                             g.tc0 = ca - cc[b]; // (ra == rc[a]: rows are cut at every window boundary)
                             size_t t = tbase[a] + b;
-                            tsegs[t].push_back(g);
+                            fsegs.push_back(g), ftile.push_back((uint32_t)t), tstart[t + 1]++;
                             tcost[t] += (double)round_up(g.mr, 16) * round_up(g.nc, 16) * round_up(g.K, 16) + 65536.0;
                             gg_macs += (uint64_t)g.mr * g.nc * g.K;
                         }
                     }
+                }
+                pc.lap("6c segments");
+                const size_t seg_base = out.gsegs.size();
+                {
+                    for (size_t t = 0; t < tbase[nrt]; t++)
+                        tstart[t + 1] += tstart[t];
+                    tvec<uint32_t> pos(tstart.begin(), tstart.end() - 1, mem);
+                    out.gsegs.resize(seg_base + fsegs.size());
+                    for (size_t k = 0; k < fsegs.size(); k++)
+                        out.gsegs[seg_base + pos[ftile[k]]++] = fsegs[k];
                 }
                 for (int a = 0; a < nrt; a++) {
                     const std::vector<int> &cc = *ccs[a];
                     const int nct = (int)cc.size() - 1;
                     for (int b = 0; b < nct; b++) {
                         size_t t = tbase[a] + b;
-                        if (tsegs[t].empty())
+                        if (tstart[t + 1] == tstart[t])
                             continue;
                         DTile dt{};
                         dt.sigma_off = c.base + (uint64_t)rc[a] * c.ld + cc[b];
@@ -783,15 +934,15 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         int n_it = std::max(1, (int)std::lround(tcost[t] / per_item));
                         double per = tcost[t] / n_it, acc = 0;
                         int made = 0;
-                        uint32_t begin = (uint32_t)out.gsegs.size();
-                        for (size_t k = 0; k < tsegs[t].size(); k++) {
-                            const GSeg &g = tsegs[t][k];
-                            out.gsegs.push_back(g);
+                        uint32_t begin = (uint32_t)(seg_base + tstart[t]);
+                        const uint32_t t_end = (uint32_t)(seg_base + tstart[t + 1]);
+                        for (uint32_t k = begin; k < t_end; k++) {
+                            const GSeg &g = out.gsegs[k];
                             acc += (double)round_up(g.mr, 16) * round_up(g.nc, 16) * round_up(g.K, 16) + 65536.0;
-                            bool last = k + 1 == tsegs[t].size();
+                            bool last = k + 1 == t_end;
                             if (last || (acc >= per * (made + 1) && made + 1 < n_it)) {
                                 GItem it{};
-                                it.seg_begin = begin, it.seg_end = (uint32_t)out.gsegs.size();
+                                it.seg_begin = begin, it.seg_end = k + 1;
                                 it.out_off = slab, it.out_ld = dt.cols, it.rows = dt.rows, it.cols = dt.cols;
                                 it.alpha = 1.0, it.out_kind = 0;
                                 out.gitems.push_back(it);
@@ -813,9 +964,11 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         tile_seq++;
                     }
                 }
+                pc.lap("6d items");
                 tile_sector++;
                 i = j;
             }
+            pc.lap("6 stage-1 items");
             const uint32_t s1_end = (uint32_t)out.gitems.size();
             ss.tile_end = (uint32_t)out.gtiles.size();
             // group by tile-height variant; inside a variant, longest items first
@@ -862,15 +1015,15 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     uint32_t idx;
                     bool tall;
                 };
-                std::vector<IK> ik(n0);
+                tvec<IK> ik(n0, mem);
                 for (uint32_t q = 0; q < n0; q++) {
                     const GItem &it = out.gitems[s0_begin + q];
                     ik[q] = IK{icost(it), s0_key[q], s0_begin + q, !split0 || tall(it)};
                 }
-                std::vector<GItem> sorted;
+                tvec<GItem> sorted(mem);
                 sorted.reserve(n0);
                 for (int cl = 0; cl < 2; cl++) { // tall class, then the short one (its own launch when split0)
-                    std::vector<IK> v;
+                    tvec<IK> v(mem);
                     for (const IK &k : ik)
                         if (k.tall == (cl == 0))
                             v.push_back(k);
@@ -890,7 +1043,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         uint64_t maxc, sum;
                         uint32_t b, e;
                     };
-                    std::vector<Grp> gs;
+                    tvec<Grp> gs(mem);
                     for (uint32_t a = 0; a < v.size();) {
                         uint32_t b = a;
                         uint64_t sum = 0;
@@ -901,7 +1054,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     }
                     std::stable_sort(gs.begin(), gs.end(), [](const Grp &x, const Grp &y) { return x.maxc > y.maxc; });
                     const size_t N = v.size();
-                    std::vector<std::vector<uint32_t>> qu(8);
+                    tvec<tvec<uint32_t>> qu(8, mem);
                     size_t cap[8];
                     uint64_t load[8] = {};
                     for (size_t x = 0; x < 8; x++)
@@ -924,6 +1077,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 }
                 std::copy(sorted.begin(), sorted.end(), out.gitems.begin() + s0_begin);
             }
+            pc.lap("7 stage-0 order");
             uint32_t s1_mid = s1_begin;
             // Stage 1: longest first ACROSS sibling groups, siblings together inside a group.  Items of equal cost that
             // take the same K range (item index j) of neighbouring tiles of one sector walk the same operands: the tiles of
@@ -935,7 +1089,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     uint64_t cost;
                     uint32_t j, seq, idx;
                 };
-                std::vector<Key> keys;
+                tvec<Key> keys(mem);
                 keys.reserve(s1_end - s1_begin);
                 uint32_t seq = 0, j = 0;
                 for (uint32_t ii = s1_begin; ii < s1_end; ii++) { // (creation order: tile by tile, items of a tile in a row)
@@ -955,7 +1109,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 // g = 16 siblings per XCD and window (measured on the M=4000 plan: FETCH_SIZE -12 %, time -1 %; g = 4 ... 64
                 // within 2 % of each other; B2X_XCD_G overrides, 0 = plain cost order)
                 static const int xg = getenv("B2X_XCD_G") ? atoi(getenv("B2X_XCD_G")) : 16;
-                std::vector<GItem> sorted;
+                tvec<GItem> sorted(mem);
                 sorted.reserve(keys.size());
                 for (const Key &k : keys)
                     sorted.push_back(out.gitems[k.idx]);
@@ -963,7 +1117,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 s1_mid = s1_begin + (uint32_t)n_tall;
                 if (xg > 1) {
                     const size_t W = (size_t)8 * xg;
-                    std::vector<GItem> tmp(W);
+                    tvec<GItem> tmp(W, mem);
                     const size_t lim[3] = {0, n_tall, sorted.size()};
                     for (int cl = 0; cl < 2; cl++) // (a window never straddles the two launches)
                         for (size_t b = lim[cl]; b + W <= lim[cl + 1]; b += W) {
@@ -975,6 +1129,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 }
                 std::copy(sorted.begin(), sorted.end(), out.gitems.begin() + s1_begin);
             }
+            pc.lap("8 stage-1 order");
             auto fill = [&](uint32_t b, uint32_t mid, uint32_t e, uint32_t *v) { // [v[0], v[1]) tall, [v[1], v[last]) short tiles
                 v[0] = b, v[1] = mid;
                 for (int k = 2; k <= kGGVariants; k++)
@@ -989,6 +1144,23 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     st.macs_issued += tm * (uint64_t)round_up(it.cols, 16 * kGGCF) * (uint64_t)round_up(out.gsegs[k].K, 16);
             }
             ss.sum_end = (uint32_t)out.sum_work.size();
+            pc.lap("9 issue count");
+            if (pc.on) { // work-list shape of this super-step, per launch
+                const uint32_t lim[5] = {s0_begin, s0_mid, s1_begin, s1_mid, s1_end};
+                static const char *nm[4] = {"s0 tall", "s0 short", "s1 tall", "s1 short"};
+                for (int l = 0; l < 4; l++) {
+                    uint64_t ni = lim[l + 1] - lim[l], ns = 0, nch = 0, frag_ch = 0, rows = 0, cols = 0;
+                    for (uint32_t ii = lim[l]; ii < lim[l + 1]; ii++) {
+                        const GItem &it = out.gitems[ii];
+                        rows += it.rows, cols += it.cols;
+                        for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
+                            ns++, nch += ceil_div(out.gsegs[k].K, 16), frag_ch += (uint64_t)(variant(it) + 1) * ceil_div(out.gsegs[k].K, 16);
+                    }
+                    if (ni)
+                        fprintf(stderr, "[b2x plan] %-8s items %8llu  segs/item %6.2f  chunks/seg %5.2f  row frags/chunk %4.2f  rows %5.1f cols %5.1f\n",
+                                nm[l], (unsigned long long)ni, (double)ns / ni, (double)nch / ns, (double)frag_ch / nch, (double)rows / ni, (double)cols / ni);
+                }
+            }
             out.steps.push_back(ss);
             out.scratch_elems = std::max(out.scratch_elems, used + sum_extra);
             out.gslab_elems = std::max(out.gslab_elems, slab);
@@ -1009,7 +1181,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 key[0] = 0, key[1] = p.x_off, key[2] = p.y_off, key[3] = ((uint64_t)p.k1 << 32) | (uint32_t)p.k0,
                 key[4] = ((uint64_t)p.n0 << 32) | (uint32_t)p.lda0, key[5] = ((uint64_t)p.ldb0 << 8) | p.tb0, key[6] = 0;
         };
-        std::vector<Cand> cand;
+        tvec<Cand> cand(mem);
         {
             size_t nc = 0;
             for (const Component *c : big)
@@ -1022,9 +1194,19 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 cd.c = c, cd.wi = wi, cd.flip = false;
                 cand.push_back(cd);
             }
+        pc.lap("4 cand");
         if (allow_flip) {
             // order of each pair: stage-0 cost amortised over the pairs that would share the product + its own stage 1
+            // (the keys of both orders, in candidate order: the passes below read them in sequence and confirm a table hit with
+            // ONE access, not through candidate -> window -> pair)
+            tvec<std::array<uint64_t, 7>> keys[2] = {tvec<std::array<uint64_t, 7>>(mem), tvec<std::array<uint64_t, 7>>(mem)};
+            for (int fl = 0; fl < 2; fl++) {
+                keys[fl].resize(cand.size());
+                for (size_t q = 0; q < cand.size(); q++)
+                    make_key(ep[win[cand[q].wi].pair], fl != 0, keys[fl][q].data());
+            }
             auto group_sizes = [&](bool fl) { // size of every candidate's sharing group: hash table on the 7-word key
+                const tvec<std::array<uint64_t, 7>> &kk = keys[fl ? 1 : 0];
                 struct Slot { // 16 bytes: the table of a 10^5-pair plan stays in the last-level cache
                     uint64_t h;
                     uint32_t count, first; // first = candidate that opened the slot (+1; 0 = empty)
@@ -1032,42 +1214,40 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 size_t cap = 64;
                 while (cap < 2 * cand.size())
                     cap <<= 1;
-                std::vector<Slot> tab(cap, Slot{0, 0, 0});
-                std::vector<uint32_t> slot_of(cand.size());
+                tvec<Slot> tab(cap, Slot{0, 0, 0}, mem);
+                tvec<uint32_t> slot_of(cand.size(), mem);
                 for (size_t q = 0; q < cand.size(); q++) {
-                    uint64_t key[7], k2[7];
-                    make_key(ep[win[cand[q].wi].pair], fl, key);
+                    const uint64_t *key = kk[q].data();
                     uint64_t h = 0x9E3779B97F4A7C15ull;
                     for (int k = 0; k < 7; k++)
                         h = (h ^ key[k]) * 0xBF58476D1CE4E5B9ull, h ^= h >> 29;
                     size_t i = (size_t)h & (cap - 1);
                     while (tab[i].first != 0) {
-                        if (tab[i].h == h) { // confirm on the full key of the slot's first member
-                            make_key(ep[win[cand[tab[i].first - 1].wi].pair], fl, k2);
-                            if (std::equal(key, key + 7, k2))
-                                break;
-                        }
+                        if (tab[i].h == h && kk[tab[i].first - 1] == kk[q]) // (confirmed on the full key of the slot's first member)
+                            break;
                         i = (i + 1) & (cap - 1);
                     }
                     if (tab[i].first == 0)
                         tab[i].h = h, tab[i].first = (uint32_t)q + 1;
                     tab[i].count++, slot_of[q] = (uint32_t)i;
                 }
-                std::vector<uint32_t> sz(cand.size());
+                tvec<uint32_t> sz(cand.size(), mem);
                 for (size_t q = 0; q < cand.size(); q++)
                     sz[q] = tab[slot_of[q]].count;
                 return sz;
             };
-            const std::vector<uint32_t> g0 = group_sizes(false), g1 = group_sizes(true);
+            const tvec<uint32_t> g0 = group_sizes(false), g1 = group_sizes(true);
             for (size_t q = 0; q < cand.size(); q++) {
                 const b2x_pair &p = ep[win[cand[q].wi].pair];
                 const double cur_c = (double)p.k1 * p.k0 * p.n0 / g0[q] + (double)p.m1 * p.k1 * p.n0;
                 const double alt_c = (double)p.m1 * p.k1 * p.k0 / g1[q] + (double)p.m1 * p.k0 * p.n0;
                 cand[q].flip = alt_c < 0.95 * cur_c;
+                std::copy(keys[cand[q].flip ? 1 : 0][q].begin(), keys[cand[q].flip ? 1 : 0][q].end(), cand[q].key);
             }
-        }
-        for (Cand &cd : cand)
-            make_key(ep[win[cd.wi].pair], cd.flip, cd.key);
+        } else
+            for (Cand &cd : cand)
+                make_key(ep[win[cd.wi].pair], cd.flip, cd.key);
+        pc.lap("4 group sizes");
         if (allow_flip && opt && opt->presum == 1) {
             // Operator pre-sums (off by default: +2 % at M=4000, +8 % at M=500, -2 % at M=1000 on the Cr2 plan, for 36 GB
             // of plan-owned memory at M=4000; the per-step sums of W products above catch most of the same redundancy).  Pairs with the SAME stage-0 product and the SAME psi' window differ only in their second
@@ -1078,7 +1258,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 uint64_t k[10];
                 uint32_t q;
             };
-            std::vector<PK> pk(cand.size());
+            tvec<PK> pk(cand.size(), mem);
             for (size_t q = 0; q < cand.size(); q++) {
                 const Window &w = win[cand[q].wi];
                 const b2x_pair &p = ep[w.pair];
@@ -1092,7 +1272,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         return x.k[k] < y.k[k];
                 return false;
             });
-            std::vector<uint8_t> dead(cand.size(), 0);
+            tvec<uint8_t> dead(cand.size(), 0, mem);
             for (size_t a2 = 0; a2 < pk.size();) {
                 size_t b2 = a2 + 1;
                 while (b2 < pk.size() && std::equal(pk[a2].k, pk[a2].k + 10, pk[b2].k))
@@ -1134,7 +1314,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 a2 = b2;
             }
             if (aux_len) {
-                std::vector<Cand> keep;
+                tvec<Cand> keep(mem);
                 for (size_t q = 0; q < cand.size(); q++)
                     if (!dead[q])
                         keep.push_back(cand[q]);
@@ -1142,14 +1322,41 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 used = aux_len;
             }
         }
+        pc.lap("4 keys+presum");
         auto key_less = [](const Cand &x, const Cand &y) {
             for (int k = 0; k < 7; k++)
                 if (x.key[k] != y.key[k])
                     return x.key[k] < y.key[k];
             return false;
         };
-        if (allow_flip) // (keep_order = 1 replays the reference pair by pair: sector order, no sharing)
-            std::stable_sort(cand.begin(), cand.end(), key_less);
+        if (allow_flip) { // (keep_order = 1 replays the reference pair by pair: sector order, no sharing)
+            // the order of std::stable_sort(cand, key_less), from a sort of 32-byte records (leading key words + position)
+            struct SK {
+                uint64_t a, b, c;
+                uint32_t idx;
+            };
+            tvec<SK> sk(cand.size(), mem);
+            for (size_t q = 0; q < cand.size(); q++)
+                sk[q] = SK{cand[q].key[0], cand[q].key[1], cand[q].key[2], (uint32_t)q};
+            std::sort(sk.begin(), sk.end(), [&](const SK &x, const SK &y) {
+                if (x.a != y.a)
+                    return x.a < y.a;
+                if (x.b != y.b)
+                    return x.b < y.b;
+                if (x.c != y.c)
+                    return x.c < y.c;
+                if (key_less(cand[x.idx], cand[y.idx]))
+                    return true;
+                if (key_less(cand[y.idx], cand[x.idx]))
+                    return false;
+                return x.idx < y.idx;
+            });
+            tvec<Cand> sorted(cand.size(), mem);
+            for (size_t q = 0; q < cand.size(); q++)
+                sorted[q] = cand[sk[q].idx];
+            cand.swap(sorted);
+        }
+        pc.lap("4 pair order + keys");
         uint64_t last_off = 0;
         for (size_t q = 0; q < cand.size(); q++) {
             const Cand &cd = cand[q];
@@ -1193,6 +1400,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     stage_residual_reads(out, std::max(arena_cap, arena_len), psi_len);
     st.device_bytes = (out.scratch_elems + out.gslab_elems) * 8 + out.gsegs.size() * sizeof(GSeg) +
                       out.gitems.size() * sizeof(GItem) + out.gtiles.size() * sizeof(DTile) + slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
+    if (pc.on)
+        fprintf(stderr, "[b2x plan] segments %zu (capacity %zu), items %zu (capacity %zu), sum work %zu entries %zu, pads %zu\n", out.gsegs.size(), out.gsegs.capacity(), out.gitems.size(), out.gitems.capacity(), out.sum_work.size(), out.sum_entries.size(), out.scratch_pads.size());
+    pc.lap("a closing");
+    pc.report();
     return B2X_OK;
 }
 

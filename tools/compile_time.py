@@ -12,10 +12,11 @@ pf = read_struct_npz(os.path.join(ROOT, "tests", "golden", sys.argv[1]))
 f = int(sys.argv[2])
 if f > 1:
     pf = synth.scale_plan(pf, f)
-for i in range(2):
+t_c = 1e9
+for i in range(7):  # (minimum of 7: the container's cores are shared)
     t = time.perf_counter()
     st, fb = hooks.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, None, None, None, arena_len=pf.arena_len)
-    t_c = time.perf_counter() - t
+    t_c = min(t_c, time.perf_counter() - t)
 import torch
 if torch.cuda.is_available():
     capi.device_init(0)
