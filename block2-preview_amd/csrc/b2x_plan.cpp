@@ -89,6 +89,57 @@ struct ArenaScope { // rewinds the arena when the compilation ends, however it e
     ~ArenaScope() { a.rewind(); }
 };
 template <class T> using tvec = std::pmr::vector<T>;
+// the reserved (still untouched) storage of a large output list: ask for 2 MB pages, 512 x fewer first-touch faults
+inline void advise_huge(const void *p, size_t bytes) {
+    const uintptr_t two_mb = (uintptr_t)2 << 20, b = ((uintptr_t)p + two_mb - 1) & ~(two_mb - 1), e = ((uintptr_t)p + bytes) & ~(two_mb - 1);
+    if (e > b)
+        (void)madvise((void *)b, (size_t)(e - b), MADV_HUGEPAGE);
+}
+
+// v reordered as std::stable_sort by the NK key words T::k would order it, for lists that fall into FEW groups of equal
+// keys (the 155 728 records of the Cr2 noise list: 1 400 groups): one hashing pass assigns groups, only the group
+// representatives are sorted, the members follow in their original order.
+template <int NK, class T> void group_sort(std::vector<T> &v, std::pmr::memory_resource *mem) {
+    const size_t n = v.size();
+    if (n < 2)
+        return;
+    struct Slot {
+        uint64_t h;
+        uint32_t rep, id; // rep = first member (+1; 0 = empty)
+    };
+    size_t cap = 64;
+    while (cap < 2 * n)
+        cap <<= 1;
+    tvec<Slot> tab(cap, Slot{0, 0, 0}, mem);
+    tvec<uint32_t> gid(n, mem), reps(mem), count(mem);
+    for (size_t x = 0; x < n; x++) {
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (int k = 0; k < NK; k++)
+            h = (h ^ v[x].k[k]) * 0xBF58476D1CE4E5B9ull, h ^= h >> 29;
+        size_t i = (size_t)h & (cap - 1);
+        while (tab[i].rep != 0 && !(tab[i].h == h && std::equal(v[x].k, v[x].k + NK, v[tab[i].rep - 1].k)))
+            i = (i + 1) & (cap - 1);
+        if (tab[i].rep == 0) {
+            tab[i] = Slot{h, (uint32_t)x + 1, (uint32_t)reps.size()};
+            reps.push_back((uint32_t)x), count.push_back(0);
+        }
+        gid[x] = tab[i].id, count[tab[i].id]++;
+    }
+    tvec<uint32_t> order(reps.size(), mem); // groups by key
+    for (size_t g = 0; g < order.size(); g++)
+        order[g] = (uint32_t)g;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return std::lexicographical_compare(v[reps[a]].k, v[reps[a]].k + NK, v[reps[b]].k, v[reps[b]].k + NK);
+    });
+    tvec<size_t> start(reps.size(), mem);
+    size_t pos = 0;
+    for (uint32_t g : order)
+        start[g] = pos, pos += count[g];
+    std::vector<T> out(n);
+    for (size_t x = 0; x < n; x++)
+        out[start[gid[x]]++] = v[x];
+    v.swap(out);
+}
 
 // (development aid, B2X_PLAN_DEBUG=1) wall time of the phases of compile_plan, on stderr
 struct PhaseClock {
@@ -178,7 +229,7 @@ const std::vector<int> &wave_cuts_m(int total, int tile) {
 // Sort the output windows and merge overlapping ones into disjoint components (sectors of the output vector with a
 // common leading dimension).  `fallback` is set when the windows cannot be laid on a common grid.
 std::vector<Component> build_components(std::vector<Window> &win, bool &fallback, std::string &reason) {
-    std::stable_sort(win.begin(), win.end(), [](const Window &a, const Window &b) { return a.off < b.off; });
+    std::stable_sort(win.begin(), win.end(), [](const Window &a, const Window &b) { return a.off < b.off; }); // (mostly pre-sorted input: the merge sort wins)
     std::vector<Component> comps;
     size_t i = 0;
     while (i < win.size()) {
@@ -616,6 +667,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 est += ((size_t)ceil_div(p.m1, kGGTileM) + 2) * ct + ((size_t)ceil_div(std::max(p.k1, p.m1), kGGTileM) + 1) * ct;
             }
             out.gsegs.reserve(est), out.gitems.reserve(est);
+            advise_huge(out.gsegs.data(), est * sizeof(GSeg)), advise_huge(out.gitems.data(), est * sizeof(GItem));
         }
         tvec<b2x_pair> ep(pairs, pairs + n_pairs, mem);
         tvec<uint8_t> zsrc(n_pairs, 0, mem), ysrc(n_pairs, 0, mem);
@@ -660,7 +712,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             struct BGroup {
                 uint32_t id, row_tiles;
             };
-            std::unordered_map<uint64_t, BGroup> bgroups;
+            std::pmr::unordered_map<uint64_t, BGroup> bgroups(mem);
+            bgroups.reserve(cur.size());
             auto s0_group = [&](uint64_t b_id, size_t n_row_tiles) -> BGroup {
                 auto it = bgroups.find(b_id);
                 if (it == bgroups.end())
@@ -817,11 +870,11 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         m.k[5] = cur[q].flip ? (((uint64_t)p.ldb0 << 8) | p.tb0 | ((uint64_t)ysrc[w.pair] << 60))
                                              : (((uint64_t)p.lda1 << 8) | p.ta1 | ((uint64_t)zsrc[w.pair] << 60));
                     }
-                    std::stable_sort(mk.begin(), mk.end(), [](const MK &x, const MK &y) {
+                    std::sort(mk.begin(), mk.end(), [](const MK &x, const MK &y) {
                         for (int k = 0; k < 6; k++)
                             if (x.k[k] != y.k[k])
                                 return x.k[k] < y.k[k];
-                        return false;
+                        return x.q < y.q;
                     });
                     for (size_t a = 0; a < mk.size();) {
                         size_t b = a + 1;
@@ -1030,14 +1083,14 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     if (cl == 0)
                         s0_mid = s0_begin + (uint32_t)v.size();
                     if (!s0_local || v.size() < 64) {
-                        std::stable_sort(v.begin(), v.end(), [](const IK &x, const IK &y) { return x.cost > y.cost; });
+                        std::sort(v.begin(), v.end(), [](const IK &x, const IK &y) { return x.cost != y.cost ? x.cost > y.cost : x.idx < y.idx; });
                         for (const IK &k : v)
                             sorted.push_back(out.gitems[k.idx]);
                         continue;
                     }
                     // groups: members together (longest first inside), groups by their longest member
-                    std::stable_sort(v.begin(), v.end(), [](const IK &x, const IK &y) {
-                        return x.grp != y.grp ? x.grp < y.grp : x.cost > y.cost;
+                    std::sort(v.begin(), v.end(), [](const IK &x, const IK &y) {
+                        return x.grp != y.grp ? x.grp < y.grp : (x.cost != y.cost ? x.cost > y.cost : x.idx < y.idx);
                     });
                     struct Grp {
                         uint64_t maxc, sum;
@@ -1052,7 +1105,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         gs.push_back(Grp{v[a].cost, sum, a, b});
                         a = b;
                     }
-                    std::stable_sort(gs.begin(), gs.end(), [](const Grp &x, const Grp &y) { return x.maxc > y.maxc; });
+                    std::sort(gs.begin(), gs.end(), [](const Grp &x, const Grp &y) { return x.maxc != y.maxc ? x.maxc > y.maxc : x.b < y.b; });
                     const size_t N = v.size();
                     tvec<tvec<uint32_t>> qu(8, mem);
                     size_t cap[8];
@@ -1099,12 +1152,12 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                     seq = tile_of_item[ii - s1_begin];
                     keys.push_back(Key{icost(it), j, seq, ii});
                 }
-                std::stable_sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) {
+                std::sort(keys.begin(), keys.end(), [](const Key &x, const Key &y) {
                     if (x.cost != y.cost)
                         return x.cost > y.cost;
                     if (x.j != y.j)
                         return x.j < y.j;
-                    return x.seq < y.seq;
+                    return x.seq != y.seq ? x.seq < y.seq : x.idx < y.idx;
                 });
                 // g = 16 siblings per XCD and window (measured on the M=4000 plan: FETCH_SIZE -12 %, time -1 %; g = 4 ... 64
                 // within 2 % of each other; B2X_XCD_G overrides, 0 = plain cost order)
@@ -1413,20 +1466,23 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     out.seg_scaled = true;
     b2x_plan_stats &st = out.stats;
     st.n_pairs = n_gemms, st.psi_len = in_len, st.sigma_len = out_len;
+    static thread_local ScratchArena mem_arena; // (temporaries, see compile_plan)
+    ScratchArena *const mem = &mem_arena;
+    ArenaScope mem_scope{mem_arena};
     std::vector<std::pair<uint64_t, uint64_t>> opext;
     for (size_t i = 0; i < n_gemms; i++) {
         const b2x_gemm &g = gemms[i];
-        const std::string id = "gemm " + std::to_string(i);
+        auto id = [i]() { return "gemm " + std::to_string(i); }; // (built on error only: 10^5 records pass through here)
         if (g.ta > 1 || g.tb > 1 || g.a_src > 1 || g.b_src > 1) {
-            err = id + ": unsupported transpose / source flags";
+            err = id() + ": unsupported transpose / source flags";
             return B2X_ERR_INVALID;
         }
         if (g.m <= 0 || g.n <= 0 || g.k <= 0) {
-            err = id + ": dimensions must be positive";
+            err = id() + ": dimensions must be positive";
             return B2X_ERR_INVALID;
         }
         if (g.lda < (g.ta ? g.m : g.k) || g.ldb < (g.tb ? g.k : g.n) || g.ldc < g.n) {
-            err = id + ": leading dimension smaller than row length";
+            err = id() + ": leading dimension smaller than row length";
             return B2X_ERR_INVALID;
         }
         uint64_t ea = g.ta ? (uint64_t)(g.k - 1) * g.lda + g.m : (uint64_t)(g.m - 1) * g.lda + g.k;
@@ -1434,7 +1490,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
         uint64_t ec = (uint64_t)(g.m - 1) * g.ldc + g.n;
         if (g.a_off + ea > (g.a_src ? (uint64_t)in_len : arena_len) || g.b_off + eb > (g.b_src ? (uint64_t)in_len : arena_len) ||
             g.c_off + ec > out_len) {
-            err = id + ": operand runs past the end of the input / output vector or the arena";
+            err = id() + ": operand runs past the end of the input / output vector or the arena";
             return B2X_ERR_INVALID;
         }
         st.macs += (uint64_t)g.m * g.n * g.k;
@@ -1442,6 +1498,21 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
             opext.emplace_back(g.a_off, ea);
         if (!g.b_src)
             opext.emplace_back(g.b_off, eb);
+    }
+    { // (distinct (offset, extent) first, as in compile_plan)
+        size_t cap = 1024;
+        while (cap < 2 * opext.size())
+            cap <<= 1;
+        tvec<std::pair<uint64_t, uint64_t>> set(cap, std::make_pair(~(uint64_t)0, (uint64_t)0), mem);
+        std::vector<std::pair<uint64_t, uint64_t>> uniq;
+        for (const auto &e : opext) {
+            size_t i = (size_t)((e.first * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+            while (set[i].first != ~(uint64_t)0 && set[i] != e)
+                i = (i + 1) & (cap - 1);
+            if (set[i].first == ~(uint64_t)0)
+                set[i] = e, uniq.push_back(e);
+        }
+        opext.swap(uniq);
     }
     std::sort(opext.begin(), opext.end());
     {
@@ -1488,12 +1559,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
             m.k[6] = right ? g.ta : g.tb; // members of a group are stored in the same orientation (S is built in it)
             mk.push_back(m);
         }
-        std::stable_sort(mk.begin(), mk.end(), [](const MK &x, const MK &y) {
-            for (int k = 0; k < 7; k++)
-                if (x.k[k] != y.k[k])
-                    return x.k[k] < y.k[k];
-            return false;
-        });
+        group_sort<7>(mk, mem);
         uint64_t s_used = 0;
         std::vector<b2x_gemm> merged;
         // Sums already formed, by member set: the same operator blocks meet several psi blocks (one per quantum number of
@@ -1760,25 +1826,25 @@ int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, si
     };
     for (size_t i = 0; i < n_terms; i++) {
         const b2x_outer_term &t = terms[i];
-        const std::string id = "outer term " + std::to_string(i);
+        auto id = [i]() { return "outer term " + std::to_string(i); }; // (built on error only)
         if (t.m <= 0 || t.n <= 0 || t.ldc < t.n || t.a_src > 2 || t.b_src > 2 || t.a_rs < 0 || t.a_cs < 0 || t.b_rs < 0 ||
             t.b_cs < 0) {
-            err = id + ": bad dimensions, strides or source flags";
+            err = id() + ": bad dimensions, strides or source flags";
             return B2X_ERR_INVALID;
         }
         int64_t lo, hi;
         span(t.m, t.n, t.a_rs, t.a_cs, lo, hi);
         if (t.a_src < 2 && t.a_off + (uint64_t)hi >= (t.a_src ? (uint64_t)in_len : arena_len)) {
-            err = id + ": A operand out of range";
+            err = id() + ": A operand out of range";
             return B2X_ERR_INVALID;
         }
         span(t.m, t.n, t.b_rs, t.b_cs, lo, hi);
         if (t.b_src < 2 && t.b_off + (uint64_t)hi >= (t.b_src ? (uint64_t)in_len : arena_len)) {
-            err = id + ": B operand out of range";
+            err = id() + ": B operand out of range";
             return B2X_ERR_INVALID;
         }
         if (t.c_off + (uint64_t)(t.m - 1) * t.ldc + t.n > out_len) {
-            err = id + ": output window out of range";
+            err = id() + ": output window out of range";
             return B2X_ERR_INVALID;
         }
     }

@@ -146,3 +146,24 @@ def test_reference_plans_never_take_the_atomic_fallback(built, fn):
         st, fb = hooks.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, None, None, None,
                                                  arena_len=pf.arena_len, **kw)
         assert not fb and st["fallback"] == 0 and st["n_staged"] <= 8 and st["macs"] == pf.macs
+
+
+def test_compilations_are_independent_of_what_was_compiled_before(built):
+    """The compiler's temporaries live in a per-thread arena that is rewound, not released, between compilations
+    (b2x_plan.cpp ScratchArena): a plan compiled after OTHER plans (larger, smaller, forced options) must give the bits
+    it gives when compiled first."""
+    rng = np.random.default_rng(77)
+    small = fill_plan(synth.random_rotate_plan(rng, n_sectors=3, max_dim=40, max_terms=3), 1)
+    large = fill_plan(synth.random_rotate_plan(rng, n_sectors=6, max_dim=200, max_terms=8), 2)
+
+    def run(pf, **kw):
+        sig = np.zeros(pf.sigma_len)
+        st, fb = hooks.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, pf.arena, pf.psi, sig, 1.0, **kw)
+        assert not fb
+        return sig, st
+
+    first, st0 = run(small)
+    for pf, kw in [(large, {}), (large, dict(keep_order=1)), (small, dict(scratch_mb=1)), (large, dict(presum=1))]:
+        run(pf, **kw)
+        again, st1 = run(small)
+        assert np.array_equal(first, again) and st0 == st1
