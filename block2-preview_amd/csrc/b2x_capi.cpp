@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <string>
@@ -567,14 +568,26 @@ int b2x_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_pairs, cons
             return B2X_OK;
         }
     }
+    const bool dbg = getenv("B2X_PLAN_DEBUG") != nullptr; // (development aid: host time of the steps, on stderr)
+    auto now = []() { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     CompiledPlan cp;
     std::string err;
     int rc = compile_plan(n_pairs, pairs, psi_len, sigma_len, arena->len, arena->cap, opt, cp, err);
     if (rc != B2X_OK)
         return fail(rc, "b2x_plan_create: " + err);
+    const auto t1 = now();
     rc = plan_upload(out, arena, cp, n_pairs, pairs, psi_len, sigma_len, opt);
-    if (rc == B2X_OK && use_cache && (*out)->cacheable && !(*out)->fallback)
-        make_key((*out)->key, 0, pairs, n_pairs, sizeof(b2x_pair), psi_len, sigma_len, arena, opt, true);
+    const auto t2 = now();
+    if (rc == B2X_OK && use_cache && (*out)->cacheable && !(*out)->fallback) { // (the hashes of the lookup above; the records are kept for the byte comparison of a later hit)
+        (*out)->key = key;
+        (*out)->key.blob.assign((const unsigned char *)pairs, (const unsigned char *)pairs + n_pairs * sizeof(b2x_pair));
+    }
+    if (dbg)
+        fprintf(stderr, "[b2x plan] create: compile %.2f ms, upload + bind %.2f ms, cache key %.2f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, now()));
     return rc;
 }
 
@@ -605,8 +618,10 @@ int b2x_gemm_plan_create(b2x_plan **out, const b2x_arena *arena, size_t n_gemms,
     if (rc != B2X_OK)
         return fail(rc, "b2x_gemm_plan_create: " + err);
     rc = plan_upload(out, arena, cp, 0, nullptr, in_len, out_len, nullptr);
-    if (rc == B2X_OK && use_cache && (*out)->cacheable)
-        make_key((*out)->key, 1, gemms, n_gemms, sizeof(b2x_gemm), in_len, out_len, arena, opt, true);
+    if (rc == B2X_OK && use_cache && (*out)->cacheable) {
+        (*out)->key = key;
+        (*out)->key.blob.assign((const unsigned char *)gemms, (const unsigned char *)gemms + n_gemms * sizeof(b2x_gemm));
+    }
     return rc;
 }
 

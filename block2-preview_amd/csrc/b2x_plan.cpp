@@ -859,11 +859,17 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                         uint64_t k[6];
                         uint32_t q;
                     };
-                    tvec<MK> mk(j - i, mem);
+                    tvec<MK> mk(mem);
+                    mk.reserve(j - i);
                     for (size_t q = i; q < j; q++) {
                         const Window &w = win[cur[q].wi];
                         const b2x_pair &p = ep[w.pair];
-                        MK &m = mk[q - i];
+                        // (a group is only summed where dim (g - 1)/(g + 1) > 64, below: pairs whose dim is <= 64 — every pair
+                        // of a small-M plan — never qualify and need not be keyed and sorted)
+                        if ((cur[q].flip ? p.n0 : p.m1) <= 64)
+                            continue;
+                        mk.emplace_back();
+                        MK &m = mk.back();
                         m.q = (uint32_t)q;
                         m.k[0] = cur[q].flip, m.k[1] = cur[q].flip ? p.y_off : p.z_off, m.k[2] = w.off;
                         m.k[3] = ((uint64_t)p.m1 << 32) | (uint32_t)p.n0, m.k[4] = cur[q].flip ? (uint64_t)p.k0 : (uint64_t)p.k1;
