@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void hpsi_wave(const DPart *__restrict__ pa
 // private to a wave and are prefetched one chunk ahead straight into registers.  Row tiles are cut at the
 // row-slice boundaries of the sector, so a segment's rows always cover its tile: only columns (B side)
 // and the k tail need masking, and both are applied to the B registers.
-template <int TMF, int CF, int NW, int KC, bool SB>
+template <int TMF, int CF, int NW, int KC, bool SB, int CW = CF> // CW = column fragments per wave in the tile LAYOUT, CF <= CW of them active
 __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr, double *lds, const GSeg *__restrict__ segs,
                                         const double *__restrict__ arena, const double *__restrict__ psi,
                                         double *__restrict__ scratch, double *__restrict__ slabs) {
@@ -292,7 +292,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
         for (int j = 0; j < NI; j++)
             lane_consts(j, h_rowc[j], h_kofs[j], h_rk[j], h_kl[j]);
     }
-    const int cbase0 = wave * (CF * 16) + c; // this lane's column in the tile (first column fragment)
+    const int cbase0 = wave * (CW * 16) + c; // this lane's column in the tile (first column fragment)
     auto lane_offsets = [&](const GSeg &S, int kb, bool part) __attribute__((always_inline)) {
         const int n = S.K - kb;                                 // valid k of this chunk (part: n < KC)
         const uint32_t kcl = part ? (uint32_t)(n - 1) : 0xFFFFu; // largest k offset that may be fetched
@@ -438,7 +438,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
     // granularity) only helps staging the A chunks: same segment walk and the same barriers as its workgroup, but no B
     // loads and no MFMAs, so its SIMD is left to the wave of the other workgroup on the CU.  The branch is taken once,
     // before the main loop, so the MFMA path below stays one straight loop.
-    if (wave * (CF * 16) >= item.cols) {
+    if (wave * (CW * 16) >= item.cols) {
         uint32_t hi = item.seg_begin;
         if (hi < item.seg_end) {
             GSeg S = segs[hi];
@@ -548,7 +548,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
     double *out = (fin.out_kind ? scratch : slabs) + fin.out_off;
 #pragma unroll
     for (int q = 0; q < CF; q++) {
-        const int col = wave * (CF * 16) + q * 16 + c;
+        const int col = wave * (CW * 16) + q * 16 + c;
         if (col < fin.cols) {
             // rows g, g + 4, g + 8, ...: a running pointer (one add per store, no 64-bit multiply); only the tile's last
             // row fragment can be cut short (rows > 16 (TMF - 1) by construction), so only it tests the row
@@ -587,15 +587,27 @@ __global__ __launch_bounds__(NW * 64, TMAX <= 3 ? 4 : (TMAX <= 5 ? 3 : 2)) void 
                                                          double *__restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) double lds[2 * TMAX * 16 * KC];
     const GItem item = items[blockIdx.x];
+    // A wave whose share of the tile is at most 16 columns wide (narrow sectors, the last column tile of a sector) runs the
+    // body with ONE active column fragment: half the MFMAs and half the B loads of the padded two (same segment walk and
+    // barriers as the other waves of its workgroup, same register budget).
+    const int wcols = item.cols - (int)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * (CF * 16);
+    const bool half = CF == 2 && wcols > 0 && wcols <= 16;
 #define B2X_GG_CASE(T)                                                                                                 \
     case T:                                                                                                            \
-        if constexpr (T <= TMAX)                                                                                       \
-            gg_body<T, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);               \
+        if constexpr (T <= TMAX) {                                                                                     \
+            if (half)                                                                                                  \
+                gg_body<T, (CF == 2 ? 1 : CF), NW, KC, SB, CF>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs); \
+            else                                                                                                       \
+                gg_body<T, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);           \
+        }                                                                                                              \
         break;
     switch ((item.rows + 15) >> 4) { // row fragments of the tile
         B2X_GG_CASE(1) B2X_GG_CASE(2) B2X_GG_CASE(3) B2X_GG_CASE(4) B2X_GG_CASE(5) B2X_GG_CASE(6) B2X_GG_CASE(7)
     default:
-        gg_body<TMAX, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);
+        if (half)
+            gg_body<TMAX, (CF == 2 ? 1 : CF), NW, KC, SB, CF>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);
+        else
+            gg_body<TMAX, CF, NW, KC, SB>(item, items + blockIdx.x, lds, segs, arena, psi, scratch, slabs);
     }
 #undef B2X_GG_CASE
 }

@@ -41,4 +41,5 @@ torch.cuda.synchronize()
 plan.execute_device(psi.data_ptr(), sig.data_ptr(), 1.0, 0)
 torch.cuda.synchronize()
 st = plan.stats
-print("PMC_PROBE workload=%s macs=%d op_bytes=%d psi_bytes=%d scale=%d" % (arg, st["macs"], st["op_elems_unique"] * 8, full.psi_len * 8, scale))
+print("PMC_PROBE workload=%s macs=%d op_bytes=%d psi_bytes=%d scale=%d macs_executed=%d macs_issued=%d (SQ_INSTS_MFMA of the gg_kernel launches x 1024 should equal macs_issued)"
+      % (arg, st["macs"], st["op_elems_unique"] * 8, full.psi_len * 8, scale, st["macs_executed"], st["macs_issued"]))
