@@ -483,6 +483,9 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
         fetch(0, lds);
         commit();
         bool cur_kmaj = s_kmaj;
+        // A chunk with at most KC/2 valid k (the tail of a segment whose K is not a multiple of the chunk depth; a whole
+        // segment at tiny K) runs the first half of its k-steps only: the B fragments of the other half are zero.
+        bool cur_short = S.K <= KC / 2;
         __syncthreads(); // drains the DMA (vmcnt(0)) and publishes the image
         // SIMD partners must not run in lockstep (same program, same barrier: both would issue loads, then both MFMAs,
         // leaving the matrix pipe idle in the load phase of both).  With 4-wave workgroups (the shipped configuration)
@@ -527,13 +530,15 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
                     fetch(nkb, lds + (buf ^ 1) * ABUF);
             }
             __builtin_amdgcn_sched_barrier(0);
-            compute(lds + buf * ABUF, cur_kmaj, H1{}, NH1{});
+            if (!cur_short)
+                compute(lds + buf * ABUF, cur_kmaj, H1{}, NH1{});
             __builtin_amdgcn_sched_barrier(0);
             if (!more)
                 break;
             buf ^= 1;
             commit();
             cur_kmaj = s_kmaj;
+            cur_short = S.K - nkb <= KC / 2; // (S is the segment of the chunk at nkb by now)
             __syncthreads();
             si = nsi, kb = nkb;
         }

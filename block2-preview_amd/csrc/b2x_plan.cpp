@@ -164,6 +164,11 @@ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int round_up(int a, int b) { return ceil_div(a, b) * b; }
 // columns on which a tile of `cols` columns issues MFMAs: a wave covers 16 kGGCF columns; the wave that holds the last
 // 1..16 columns runs the body with one active column fragment (gg_kernel), every other one both
+// k depth on which a segment of depth K issues MFMAs: whole 16-deep chunks, and a tail of 1..8 runs half a chunk
+inline int issued_k(int K) {
+    const int rem = K % 16;
+    return K - rem + (rem == 0 ? 0 : (rem <= 8 ? 8 : 16));
+}
 inline int issued_cols(int cols) {
     const int w = 16 * kGGCF, rem = cols % w;
     return cols - rem + (rem == 0 ? 0 : (rem <= 16 ? 16 : w));
@@ -1206,7 +1211,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 const GItem &it = out.gitems[ii];
                 uint64_t tm = (uint64_t)kGGRowUnit * (uint64_t)(variant(it) + 1);
                 for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
-                    st.macs_issued += tm * (uint64_t)issued_cols(it.cols) * (uint64_t)round_up(out.gsegs[k].K, 16);
+                    st.macs_issued += tm * (uint64_t)issued_cols(it.cols) * (uint64_t)issued_k(out.gsegs[k].K);
             }
             ss.sum_end = (uint32_t)out.sum_work.size();
             pc.lap("9 issue count");
@@ -1814,7 +1819,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
     for (const GItem &it : out.gitems) {
         uint64_t tm = (uint64_t)kGGRowUnit * (uint64_t)(variant(it) + 1);
         for (uint32_t k = it.seg_begin; k < it.seg_end; k++)
-            st.macs_issued += tm * (uint64_t)issued_cols(it.cols) * (uint64_t)round_up(out.gsegs[k].K, 16);
+            st.macs_issued += tm * (uint64_t)issued_cols(it.cols) * (uint64_t)issued_k(out.gsegs[k].K);
     }
     out.steps.push_back(ss);
     out.gslab_elems = slab;
