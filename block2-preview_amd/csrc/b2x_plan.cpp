@@ -677,8 +677,11 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                 const size_t ct = (size_t)ceil_div(p.n0, use_narrow ? kGGNarrowN : TN) + 1;
                 est += ((size_t)ceil_div(p.m1, kGGTileM) + 2) * ct + ((size_t)ceil_div(std::max(p.k1, p.m1), kGGTileM) + 1) * ct;
             }
-            out.gsegs.reserve(est), out.gitems.reserve(est);
-            advise_huge(out.gsegs.data(), est * sizeof(GSeg)), advise_huge(out.gitems.data(), est * sizeof(GItem));
+            try { // (an optimisation only: a host that refuses the address space — strict overcommit — grows the lists as before)
+                out.gsegs.reserve(est), out.gitems.reserve(est);
+                advise_huge(out.gsegs.data(), est * sizeof(GSeg)), advise_huge(out.gitems.data(), est * sizeof(GItem));
+            } catch (const std::bad_alloc &) {
+            }
         }
         tvec<b2x_pair> ep(pairs, pairs + n_pairs, mem);
         tvec<uint8_t> zsrc(n_pairs, 0, mem), ysrc(n_pairs, 0, mem);
@@ -1470,8 +1473,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     stage_residual_reads(out, std::max(arena_cap, arena_len), psi_len);
     st.device_bytes = (out.scratch_elems + out.gslab_elems) * 8 + out.gsegs.size() * sizeof(GSeg) +
                       out.gitems.size() * sizeof(GItem) + out.gtiles.size() * sizeof(DTile) + slab * 8 + st.n_parts * sizeof(DPart) + st.n_items * sizeof(DItem) + st.n_tiles * sizeof(DTile);
-    if (pc.on)
+    if (pc.on) {
         fprintf(stderr, "[b2x plan] segments %zu (capacity %zu), items %zu (capacity %zu), sum work %zu entries %zu, pads %zu\n", out.gsegs.size(), out.gsegs.capacity(), out.gitems.size(), out.gitems.capacity(), out.sum_work.size(), out.sum_entries.size(), out.scratch_pads.size());
+        fprintf(stderr, "[b2x plan] scratch arena of the compiler: %.0f MB mapped\n", (double)mem_arena.capacity() / 1048576.0);
+    }
     pc.lap("a closing");
     pc.report();
     return B2X_OK;
