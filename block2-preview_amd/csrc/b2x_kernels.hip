@@ -292,19 +292,6 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
         for (int j = 0; j < NI; j++)
             lane_consts(j, h_rowc[j], h_kofs[j], h_rk[j], h_kl[j]);
     }
-    // 1-wave workgroups with 3-4 DMA instructions per lane (32-row tiles): the four constants of every instruction are bytes
-    // (rows < 128, k < 32), kept PACKED in four registers and unpacked with a bit-field extract where they are used — the
-    // recomputation (~18 VALU per instruction, twice per segment) was a quarter of the vector instructions of a small-M item
-    constexpr bool PACK = !HOIST && NI <= 4 && NW == 1;
-    uint32_t p_rowc = 0, p_kofs = 0, p_rk = 0, p_kl = 0;
-    if constexpr (PACK) {
-#pragma unroll
-        for (int j = 0; j < NI; j++) {
-            uint32_t a, b, c2, d;
-            lane_consts(j, a, b, c2, d);
-            p_rowc |= a << (8 * j), p_kofs |= b << (8 * j), p_rk |= c2 << (8 * j), p_kl |= d << (8 * j);
-        }
-    }
     const int cbase0 = wave * (CW * 16) + c; // this lane's column in the tile (first column fragment)
     auto lane_offsets = [&](const GSeg &S, int kb, bool part) __attribute__((always_inline)) {
         const int n = S.K - kb;                                 // valid k of this chunk (part: n < KC)
@@ -314,9 +301,6 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
             uint32_t row_c, k_ofs, rk, kl;
             if constexpr (HOIST)
                 row_c = h_rowc[j], k_ofs = h_kofs[j], rk = h_rk[j], kl = h_kl[j];
-            else if constexpr (PACK)
-                row_c = (p_rowc >> (8 * j)) & 0xFFu, k_ofs = (p_kofs >> (8 * j)) & 0xFFu, rk = (p_rk >> (8 * j)) & 0xFFu,
-                kl = (p_kl >> (8 * j)) & 0xFFu;
             else
                 lane_consts(j, row_c, k_ofs, rk, kl);
             // (a segment's rows always cover its tile: S.mr == item.rows, which lane_consts clamps to)
