@@ -213,3 +213,44 @@ def test_symbolic_perturbative_noise_on_device(gpu):
         h = b2x_host.SymbolicEffectiveHamiltonian("su2" if "su2" in os.path.basename(fn) else "sz", d)
         _, v = h.perturbative_noise(d, True)
         assert _close(v, d["out_ref"]), fn
+
+
+@pytest.mark.parametrize("wide", [0, 1], ids=["64-column tiles", "128-column tiles"])
+def test_edge_widths_and_depths(gpu, wide):
+    """Widths around the 16 / 32 / 64-column boundaries of a wave's share of a tile (a share of <= 16 columns runs the body with
+    one active column fragment) and depths around the 8 / 16 boundaries of a chunk (a tail of <= 8 runs half a chunk), all four
+    transposition cases, record by record against the oracle; `wide` adds one large record so that the plan takes 128-column
+    tiles (4-wave workgroups) instead of 64-column ones."""
+    from block2_preview_amd.planfile import GEMM_DTYPE
+
+    rng = np.random.default_rng(7 + wide)
+    dims = [(m, n, k) for m in (3, 16, 37) for n in (1, 8, 16, 17, 31, 32, 33, 48, 49, 64, 65, 80, 81, 97, 113)
+            for k in (1, 7, 8, 9, 16, 17, 24, 25, 40, 41)]
+    if wide:
+        dims.append((130, 700, 300))
+    recs, in_len, arena_len, out_len = [], 0, 0, 0
+    for i, (m, n, k) in enumerate(dims):
+        ta, tb = (i >> 0) & 1, (i >> 1) & 1
+        lda, ldb = (m if ta else k) + (i % 3), (k if tb else n) + (i % 2)
+        ea = (k - 1) * lda + m if ta else (m - 1) * lda + k
+        eb = (n - 1) * ldb + k if tb else (k - 1) * ldb + n
+        a_src = (i >> 2) & 1  # the other operand comes from the other buffer
+        a_off = in_len if a_src else arena_len
+        b_off = arena_len if a_src else in_len
+        if a_src:
+            in_len, arena_len = in_len + ea, arena_len + eb
+        else:
+            arena_len, in_len = arena_len + ea, in_len + eb
+        recs.append((m, n, k, lda, ldb, n, ta, tb, a_src, 1 - a_src, 0, rng.standard_normal(), a_off, b_off, out_len))
+        out_len += m * n
+    g = np.zeros(len(recs), GEMM_DTYPE)
+    for i, r in enumerate(recs):
+        g[i] = r
+    gl = type("GL", (), dict(gemms=g, in_len=in_len, out_len=out_len))
+    arena, vin = rng.standard_normal(arena_len), rng.standard_normal(in_len)
+    ref = np.zeros(out_len)
+    oracle.gemm_list(g, arena, vin, ref, 1.25, 4)
+    for kw in (dict(keep_order=1), dict(), dict(item_macs=20000)):
+        out, st = _run(gpu, gl, arena, vin, 1.25, **kw)
+        assert st["fallback"] == 0 and st["macs_issued"] >= st["macs_executed"]
+        assert _close(out, ref), kw

@@ -298,3 +298,45 @@ def test_shared_products_and_association(gpu, seed, scratch_mb, keep_order):
     if not keep_order:  # operator pre-sums formed at plan creation
         pre, st3 = _run(gpu, pf, scratch_mb=scratch_mb, presum=1)
         assert _close(pre, ref), st3
+
+
+@pytest.mark.parametrize("wide", [0, 1], ids=["narrow plan", "wide plan"])
+def test_edge_widths_and_depths(gpu, wide):
+    """Pairs whose output widths sit around the 16 / 32 / 64-column boundaries of a wave's share of a tile and whose depths
+    (k0, k1 = m0) sit around the 8 / 16 boundaries of a chunk: the one-column-fragment body and the half-depth tail chunk of
+    gg_kernel in every workgroup class (1-, 2- and 4-wave: `wide` adds large pairs so that the plan takes 128-column tiles),
+    both transpositions of both operators, against the oracle, in the reference's order and in the compiler's."""
+    from block2_preview_amd.planfile import PAIR_DTYPE
+
+    rng = np.random.default_rng(21 + wide)
+    dims = [(m1, n, k0, k1) for m1 in (5, 16, 40) for n in (1, 8, 16, 17, 32, 33, 49, 64, 65, 81, 113)
+            for k0 in (1, 8, 9, 17, 24, 41) for k1 in (3, 8, 16, 25)]
+    if wide:
+        dims += [(150, 600, 200, 140)] * 2
+    recs, psi_len, arena_len, sigma_len = [], 0, 0, 0
+    for i, (m1, n, k0, k1) in enumerate(dims):
+        tb0, ta1 = i & 1, (i >> 1) & 1
+        lda0 = k0 + (i % 3)                      # X: k1 x k0
+        ldb0 = (k0 if tb0 else n) + (i % 2)      # Y: k0 x n (or n x k0 when transposed)
+        lda1 = (m1 if ta1 else k1) + (i % 2)     # Z: m1 x k1 (or k1 x m1)
+        ey = (n - 1) * ldb0 + k0 if tb0 else (k0 - 1) * ldb0 + n
+        ez = (k1 - 1) * lda1 + m1 if ta1 else (m1 - 1) * lda1 + k1
+        x_off, y_off = psi_len, arena_len
+        psi_len += (k1 - 1) * lda0 + k0
+        arena_len += ey
+        z_off = arena_len
+        arena_len += ez
+        recs.append((k1, n, k0, lda0, ldb0, m1, n, k1, lda1, n, 0, tb0, ta1, 0, 0, rng.standard_normal(), rng.standard_normal(),
+                     x_off, y_off, z_off, sigma_len))
+        sigma_len += m1 * n
+    p = np.zeros(len(recs), PAIR_DTYPE)
+    for i, r in enumerate(recs):
+        p[i] = r
+    psi, arena_h = rng.standard_normal(psi_len), rng.standard_normal(arena_len)
+    ref = np.zeros(sigma_len)
+    oracle.replay(p, arena_h, psi, ref, 0.5, 4)
+    pf = type("PF", (), dict(pairs=p, psi_len=psi_len, sigma_len=sigma_len, arena=arena_h, psi=psi))
+    for kw in (dict(), dict(keep_order=1), dict(two_stage=1, item_macs=30000)):
+        sig, st = _run(gpu, pf, 0.5, **kw)
+        assert st["fallback"] == 0 and st["macs_issued"] >= st["macs_executed"] > 0
+        assert _close(sig, ref), kw
