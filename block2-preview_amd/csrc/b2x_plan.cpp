@@ -11,6 +11,7 @@
 #include <memory_resource>
 #include <sys/mman.h>
 #include <cstring>
+#include <deque>
 #include <cstdlib>
 #include <numeric>
 #include <unordered_map>
@@ -216,25 +217,39 @@ std::vector<int> unit_cuts(int total, int max_units = kGGTileM / kGGRowUnit) {
 
 // The cut lists are asked for once or twice per PAIR and the dimensions repeat heavily (a few hundred distinct values per
 // plan): memoised, so that a plan of 10^5 pairs does not pay 3 x 10^5 small vector allocations.
+// (a table per parameter value — three or four of them occur — indexed by `total`: a hash lookup per call was a tenth of the
+// stage-0 list build)
+template <class F> const std::vector<int> &cuts_memo(int total, int param, F make) {
+    struct Tab {
+        int param;
+        std::deque<std::vector<int>> by_total; // (a deque: growing it leaves the references handed out earlier valid)
+    };
+    static thread_local std::vector<Tab> tabs;
+    Tab *t = nullptr;
+    for (Tab &x : tabs)
+        if (x.param == param)
+            t = &x;
+    if (!t) {
+        tabs.push_back(Tab{param, {}});
+        t = &tabs.back();
+    }
+    if (total < 0 || total >= (1 << 20)) { // (no such dimension in practice: computed, not kept)
+        static thread_local std::vector<int> big;
+        big = make(total, param);
+        return big;
+    }
+    if ((size_t)total >= t->by_total.size())
+        t->by_total.resize((size_t)total + 1);
+    std::vector<int> &v = t->by_total[total];
+    if (v.empty())
+        v = make(total, param);
+    return v;
+}
 const std::vector<int> &unit_cuts_m(int total, int max_units = kGGTileM / kGGRowUnit) {
-    static thread_local std::unordered_map<uint64_t, std::vector<int>> memo;
-    if (memo.size() > (1u << 16))
-        memo.clear();
-    const uint64_t key = ((uint64_t)(uint32_t)total << 16) | (uint64_t)(uint32_t)max_units;
-    auto it = memo.find(key);
-    if (it == memo.end())
-        it = memo.emplace(key, unit_cuts(total, max_units)).first;
-    return it->second;
+    return cuts_memo(total, max_units, [](int t, int p) { return unit_cuts(t, p); });
 }
 const std::vector<int> &wave_cuts_m(int total, int tile) {
-    static thread_local std::unordered_map<uint64_t, std::vector<int>> memo;
-    if (memo.size() > (1u << 16))
-        memo.clear();
-    const uint64_t key = ((uint64_t)(uint32_t)total << 16) | (uint64_t)(uint32_t)tile;
-    auto it = memo.find(key);
-    if (it == memo.end())
-        it = memo.emplace(key, wave_cuts(total, tile)).first;
-    return it->second;
+    return cuts_memo(total, tile, [](int t, int p) { return wave_cuts(t, p); });
 }
 
 // Sort the output windows and merge overlapping ones into disjoint components (sectors of the output vector with a
