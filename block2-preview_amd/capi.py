@@ -21,7 +21,7 @@ DECLARED_SYMBOLS = [
     "b2x_arena_create", "b2x_arena_adopt_device", "b2x_arena_resolve", "b2x_arena_len",
     "b2x_arena_device_ptr", "b2x_arena_destroy",
     "b2x_plan_create", "b2x_plan_execute", "b2x_plan_get_stats", "b2x_plan_time_kernel", "b2x_plan_destroy",
-    "b2x_plan_cache_stats", "b2x_plan_cache_clear",
+    "b2x_plan_cache_stats", "b2x_plan_cache_clear", "b2x_trim",
     "b2x_gemm_plan_create", "b2x_outer_build",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
     "b2x_vec_multi_dot", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
@@ -272,6 +272,13 @@ def plan_cache_stats():
 
 def plan_cache_clear():
     check(lib().b2x_plan_cache_clear())
+
+
+def trim():
+    """give the library's idle device memory (plan cache + buffer pool) back to the driver; returns the bytes released"""
+    v = C.c_uint64()
+    check(lib().b2x_trim(C.byref(v)))
+    return v.value
 
 
 class Comm:

@@ -44,7 +44,7 @@ static hipError_t fill_tail(double *p, uint64_t n) { // n elements: zeros (or Na
 // The big per-plan buffers (W scratch, partial slabs) are recycled between plans: a DMRG sweep creates one plan per site
 // and destroys it before the next, and a hipMalloc of the 16 GiB scratch + 16 GB of slabs of an M=4000 plan costs ~0.7 s
 // (b2x_plan_create 1.05 s against 0.30 s for the plan compiler itself; tools/compile_time.py).  A freed buffer is kept
-// (at most kPoolMax buffers, B2X_POOL_MB MiB in total, default 65536; 0 disables) and handed to the next plan that asks
+// (at most kPoolMax buffers, B2X_POOL_MB MiB in total, default a quarter of the card; 0 disables) and handed to the next plan that asks
 // for at most its size and at least half of it.  When an allocation fails the pool is emptied and the allocation retried.
 namespace {
 struct PoolBuf {
@@ -55,7 +55,15 @@ std::mutex g_pool_mu;
 std::vector<PoolBuf> g_pool;
 const size_t kPoolMax = 6;
 size_t pool_cap_bytes() {
-    static const size_t cap = (size_t)(getenv("B2X_POOL_MB") ? atoll(getenv("B2X_POOL_MB")) : 65536) << 20;
+    // B2X_POOL_MB, default: a quarter of the card's memory (72 GB on an MI355X) — the W scratch + slabs of the largest plans
+    static const size_t cap = []() -> size_t {
+        if (const char *e = getenv("B2X_POOL_MB"))
+            return (size_t)atoll(e) << 20;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess)
+            (void)hipGetLastError(), tot = (size_t)64 << 30;
+        return tot / 4;
+    }();
     return cap;
 }
 void pool_trim_locked(size_t keep_bytes) {
@@ -68,6 +76,35 @@ void pool_trim_locked(size_t keep_bytes) {
         g_pool.erase(g_pool.begin());
     }
 }
+} // namespace
+// Every hipMalloc of this library goes through dev_malloc: when the device is out of memory the idle buffers the library
+// itself holds are given back first — the buffer pool, then the parked plans of the compiled-plan cache (their work lists) —
+// and the allocation is retried.  (b2x_trim does the same on request, for other allocators of the process.)
+static size_t reclaim_cached_plans(); // defined behind the plan cache
+static hipError_t dev_malloc(void **out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess)
+        return e;
+    (void)hipGetLastError();
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        pool_trim_locked(0);
+    }
+    if ((e = hipMalloc(out, bytes)) == hipSuccess)
+        return e;
+    (void)hipGetLastError();
+    if (reclaim_cached_plans() == 0)
+        return e;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu); // (the scratch of the evicted plans went back to the pool)
+        pool_trim_locked(0);
+    }
+    e = hipMalloc(out, bytes);
+    if (e != hipSuccess)
+        (void)hipGetLastError();
+    return e;
+}
+namespace {
 hipError_t pool_alloc(void **out, size_t bytes, size_t *got) {
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -81,15 +118,8 @@ hipError_t pool_alloc(void **out, size_t bytes, size_t *got) {
             return hipSuccess;
         }
     }
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        std::lock_guard<std::mutex> lk(g_pool_mu);
-        pool_trim_locked(0);
-        e = hipMalloc(out, bytes);
-    }
     *got = bytes;
-    return e;
+    return dev_malloc(out, bytes);
 }
 void pool_free(void *p, size_t bytes) {
     if (!p)
@@ -237,7 +267,8 @@ template <typename T> static int upload(T **dst, const std::vector<T> &src) {
     if (src.empty())
         return B2X_OK;
     t_upload_bytes += src.size() * sizeof(T);
-    HIPCHK(hipMalloc((void **)dst, src.size() * sizeof(T)));
+    if (dev_malloc((void **)dst, src.size() * sizeof(T)) != hipSuccess)
+        return fail(B2X_ERR_NOMEM, "hipMalloc(work lists): out of device memory");
     HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return B2X_OK;
 }
@@ -330,6 +361,17 @@ b2x_plan *cache_take(const b2x_plan::Key &k, const void *recs) {
     return nullptr;
 }
 } // namespace
+static size_t reclaim_cached_plans() {
+    std::vector<b2x_plan *> all;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        all.swap(g_plan_cache);
+        g_cache_bytes = 0;
+    }
+    for (b2x_plan *q : all)
+        plan_free(q);
+    return all.size();
+}
 
 // upload a compiled plan (work lists + scratch / slab buffers) and hand it out
 static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPlan &cp, size_t n_pairs, const b2x_pair *pairs,
@@ -445,7 +487,24 @@ int b2x_device_sync(void) {
     return B2X_OK;
 }
 int b2x_device_alloc(void **dptr, size_t bytes) {
-    HIPCHK(hipMalloc(dptr, bytes ? bytes : 8));
+    if (!dptr)
+        return fail(B2X_ERR_INVALID, "b2x_device_alloc: null argument");
+    if (dev_malloc(dptr, bytes ? bytes : 8) != hipSuccess)
+        return fail(B2X_ERR_NOMEM, "b2x_device_alloc: out of device memory");
+    return B2X_OK;
+}
+int b2x_trim(uint64_t *bytes_released) {
+    size_t f0 = 0, f1 = 0, tot = 0;
+    (void)hipMemGetInfo(&f0, &tot);
+    reclaim_cached_plans();
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        pool_trim_locked(0);
+    }
+    (void)hipMemGetInfo(&f1, &tot);
+    (void)hipGetLastError();
+    if (bytes_released)
+        *bytes_released = f1 > f0 ? (uint64_t)(f1 - f0) : 0;
     return B2X_OK;
 }
 int b2x_device_free(void *dptr) {
@@ -483,7 +542,7 @@ int b2x_arena_create(b2x_arena **out, size_t n_ranges, const double *const *host
         tot += lens[i];
     }
     a->len = tot, a->cap = tot + kSlackElems, a->owned = true;
-    hipError_t e = hipMalloc((void **)&a->dev, a->cap * sizeof(double));
+    hipError_t e = dev_malloc((void **)&a->dev, a->cap * sizeof(double));
     if (e == hipSuccess)
         e = fill_tail(a->dev + tot, kSlackElems);
     if (e != hipSuccess) {
@@ -676,7 +735,8 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
 // graph path is not available for this plan (the caller launches directly).
 static const int kGraphUnavailable = -1000;
 static int run_plan_graph(b2x_plan *p, const double *psi, double *sigma, double scale, hipStream_t st) {
-    static const int enabled = getenv("B2X_GRAPH") ? atoi(getenv("B2X_GRAPH")) : 1;
+    const char *genv = getenv("B2X_GRAPH"); // (read per call: the tests switch it inside one process)
+    const int enabled = genv ? atoi(genv) : 1;
     if (!enabled || p->graph_failed || p->fallback || !p->stage_in.empty())
         return kGraphUnavailable;
     auto give_up = [&]() {
@@ -718,13 +778,25 @@ static int run_plan_graph(b2x_plan *p, const double *psi, double *sigma, double 
             g.node = nd, g.psi_slot = g.sigma_slot = g.scale_slot = -1;
             if (hipGraphKernelNodeGetParams(nd, &g.params) != hipSuccess || !g.params.kernelParams)
                 return give_up();
-            // every kernel of the path has at least four arguments; psi is argument 3 of the GEMM kernels
-            // (gg_kernel, hpsi_wave), (sigma, scale) are arguments 2 and 3 of hpsi_reduce
+            // which arguments are psi / sigma / scale is recorded by the launcher of each kernel (b2x_kernels.hip,
+            // note_slots): psi is argument 3 of gg_kernel and argument 4 of hpsi_wave, (sigma, scale) are arguments 2
+            // and 3 of hpsi_reduce, the sum pass has neither.  A kernel the launchers do not know, or a slot that does
+            // not hold the captured pointer, switches the graph off for this plan: a replay must never run on stale
+            // arguments.
+            KernelArgSlots sl;
+            if (!kernel_arg_slots(g.params.func, &sl))
+                return give_up();
             void **kp = g.params.kernelParams;
-            if (*(const double **)kp[3] == psi)
-                g.psi_slot = 3;
-            else if (*(double **)kp[2] == sigma)
-                g.sigma_slot = 2, g.scale_slot = 3;
+            if (sl.psi >= 0) {
+                if (*(const double **)kp[sl.psi] != psi)
+                    return give_up();
+                g.psi_slot = sl.psi;
+            }
+            if (sl.sigma >= 0) {
+                if (*(double **)kp[sl.sigma] != sigma || *(double *)kp[sl.scale] != scale)
+                    return give_up();
+                g.sigma_slot = sl.sigma, g.scale_slot = sl.scale;
+            }
             p->gnodes.push_back(g);
         }
         p->g_psi = psi, p->g_sigma = sigma, p->g_scale = scale;
@@ -756,9 +828,11 @@ int b2x_plan_execute(b2x_plan *p, const double *psi, double *sigma, double scale
         return rc == kGraphUnavailable ? run_plan(p, psi, sigma, scale, st) : rc;
     }
     if (!p->d_psi)
-        HIPCHK(hipMalloc((void **)&p->d_psi, (p->psi_len ? p->psi_len : 1) * sizeof(double)));
+        if (dev_malloc((void **)&p->d_psi, (p->psi_len ? p->psi_len : 1) * sizeof(double)) != hipSuccess)
+            return fail(B2X_ERR_NOMEM, "b2x_plan_execute: out of device memory (psi staging)");
     if (!p->d_sigma)
-        HIPCHK(hipMalloc((void **)&p->d_sigma, (p->sigma_len ? p->sigma_len : 1) * sizeof(double)));
+        if (dev_malloc((void **)&p->d_sigma, (p->sigma_len ? p->sigma_len : 1) * sizeof(double)) != hipSuccess)
+            return fail(B2X_ERR_NOMEM, "b2x_plan_execute: out of device memory (sigma staging)");
     HIPCHK(hipMemcpyAsync(p->d_psi, psi, p->psi_len * sizeof(double), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(p->d_sigma, sigma, p->sigma_len * sizeof(double), hipMemcpyHostToDevice, st));
     int rc = run_plan(p, p->d_psi, p->d_sigma, scale, st);
@@ -920,7 +994,7 @@ int b2x_diag_build(const b2x_arena *arena, size_t n_terms, const b2x_diag_term *
     if (rc == B2X_OK)
         rc = upload(&dt, dterms);
     if (rc == B2X_OK && !on_device) {
-        hipError_t e = hipMalloc((void **)&dd, diag_len * sizeof(double));
+        hipError_t e = dev_malloc((void **)&dd, diag_len * sizeof(double));
         if (e == hipSuccess)
             e = hipMemcpy(dd, diag, diag_len * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess)
@@ -967,11 +1041,11 @@ int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term
     if (rc == B2X_OK)
         rc = upload(&de, entries);
     if (rc == B2X_OK && !on_device) {
-        hipError_t e = hipMalloc((void **)&d_out, out_len * sizeof(double));
+        hipError_t e = dev_malloc((void **)&d_out, out_len * sizeof(double));
         if (e == hipSuccess)
             e = hipMemcpy(d_out, out, out_len * sizeof(double), hipMemcpyHostToDevice);
         if (e == hipSuccess && in_len) {
-            e = hipMalloc((void **)&d_in, in_len * sizeof(double));
+            e = dev_malloc((void **)&d_in, in_len * sizeof(double));
             if (e == hipSuccess)
                 e = hipMemcpy(d_in, in, in_len * sizeof(double), hipMemcpyHostToDevice);
         }

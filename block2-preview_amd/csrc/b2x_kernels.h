@@ -5,6 +5,13 @@
 
 namespace b2x {
 
+// index of the psi / sigma / scale argument of a kernel this file launches (-1: the kernel has none); false for a kernel
+// function the launchers have not seen
+struct KernelArgSlots {
+    int psi, sigma, scale;
+};
+bool kernel_arg_slots(const void *func, KernelArgSlots *out);
+
 hipError_t launch_main(int cls, const DPart *parts, const DItem *items, uint32_t n_items, const double *arena,
                        const double *psi, double *slabs, hipStream_t st);
 hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_begin, const double *arena,

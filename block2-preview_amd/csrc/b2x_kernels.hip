@@ -14,9 +14,31 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 #include <type_traits>
+#include <unordered_map>
 
 namespace b2x {
+
+// Which argument of a kernel is psi / sigma / scale: recorded by the launchers per kernel function, read back by the HIP-graph
+// replay of b2x_capi.cpp, which patches exactly those arguments of its kernel nodes (never guessed from pointer values:
+// psi is argument 3 of gg_kernel but argument 4 of hpsi_wave).
+namespace {
+std::mutex g_slots_mu;
+std::unordered_map<const void *, KernelArgSlots> g_slots;
+inline void note_slots(const void *func, int psi, int sigma, int scale) {
+    std::lock_guard<std::mutex> lk(g_slots_mu);
+    g_slots[func] = KernelArgSlots{psi, sigma, scale};
+}
+} // namespace
+bool kernel_arg_slots(const void *func, KernelArgSlots *out) {
+    std::lock_guard<std::mutex> lk(g_slots_mu);
+    auto it = g_slots.find(func);
+    if (it == g_slots.end())
+        return false;
+    *out = it->second;
+    return true;
+}
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double d4u __attribute__((ext_vector_type(4), aligned(8))); // 4 consecutive doubles, 8-byte aligned
@@ -797,6 +819,7 @@ hipError_t launch_outer(const OWork *work, uint32_t n_work, const OEntry *entrie
         return hipSuccess;
     // the sum passes: sixteen rows in flight (the HASB = false specialisation needs fewer registers, runs more waves per
     // SIMD and is SLOWER: 127 vs 113 ms on the M=4000 noise list — the transposed blocks live on L1/L2 reuse)
+    note_slots((const void *)outer_build_k<16, true>, -1, -1, -1), note_slots((const void *)outer_build_k<4, true>, -1, -1, -1);
     if (rows_in_flight >= 16)
         hipLaunchKernelGGL((outer_build_k<16, true>), dim3((n_work + 3) / 4), dim3(256), 0, st, work, n_work, entries, arena, in, out);
     else
@@ -880,6 +903,7 @@ __global__ __launch_bounds__(256) void vec_multidot_final_k(const double *partia
 template <int TMF, int K1F, int CF>
 static hipError_t launch_wave_t(const DPart *parts, const DItem *items, uint32_t n_items, const double *arena,
                                 const double *psi, double *slabs, hipStream_t st) {
+    note_slots((const void *)hpsi_wave<TMF, K1F, CF>, 4, -1, -1);
     hipLaunchKernelGGL((hpsi_wave<TMF, K1F, CF>), dim3((n_items + 3) / 4), dim3(256), 0, st, parts, items, n_items,
                        arena, psi, slabs);
     return hipGetLastError();
@@ -909,9 +933,11 @@ hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_beg
     // chunk depth 16: a 32-deep chunk halves the barriers (+2 % on uniform 1024^3 pairs) but pads every K to 32 and
     // spills at 256 VGPRs (-2 % on the M=4000 plan)
 #define B2X_GG_LAUNCH(NWV, SBV, TMAXV, B, E)                                                                           \
-    if ((E) > (B))                                                                                                     \
-    hipLaunchKernelGGL((gg_kernel<kGGCF, NWV, 16, SBV, TMAXV>), dim3((E) - (B)), dim3(NWV * 64), 0, st, segs, items + (B), \
-                       arena, psi, scratch, slabs)
+    if ((E) > (B)) {                                                                                                   \
+        note_slots((const void *)gg_kernel<kGGCF, NWV, 16, SBV, TMAXV>, 3, -1, -1);                                    \
+        hipLaunchKernelGGL((gg_kernel<kGGCF, NWV, 16, SBV, TMAXV>), dim3((E) - (B)), dim3(NWV * 64), 0, st, segs,      \
+                           items + (B), arena, psi, scratch, slabs);                                                   \
+    }
     const int nw = tile_n / (16 * kGGCF); // waves per workgroup: 4 (128-column tiles) or 2 (narrow sectors)
     const uint32_t b0 = which == 2 ? v_begin[1] : v_begin[0], b1 = v_begin[1];
     uint32_t b2 = which == 1 ? v_begin[1] : v_begin[kGGVariants];
@@ -957,6 +983,7 @@ hipError_t launch_reduce(const DTile *tiles, uint32_t n_tiles, const double *sla
     if (n_tiles == 0)
         return hipSuccess;
     const uint32_t gy = max_elems == 0 ? 16u : std::min(16u, std::max(1u, (max_elems + 255u) / 256u));
+    note_slots((const void *)hpsi_reduce, -1, 2, 3);
     hipLaunchKernelGGL(hpsi_reduce, dim3(n_tiles, gy), dim3(256), 0, st, tiles, slabs, sigma, scale);
     return hipGetLastError();
 }

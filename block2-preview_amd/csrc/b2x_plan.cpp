@@ -382,6 +382,11 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             err = "pair " + std::to_string(i) + ": leading dimension smaller than row length";
             return B2X_ERR_INVALID;
         }
+        if (std::max(std::max(p.lda0, p.ldb0), std::max(p.lda1, p.ldc1)) >= kMaxLeadingDim) {
+            // the kernels form per-lane BYTE offsets inside a tile in 32 bits with 24-bit multiplies (row < 128, k < 16)
+            err = "pair " + std::to_string(i) + ": leading dimension >= 2^22 elements is not supported";
+            return B2X_ERR_INVALID;
+        }
         uint64_t ex = (uint64_t)(p.m0 - 1) * p.lda0 + p.k0;
         uint64_t ey = p.tb0 ? (uint64_t)(p.n0 - 1) * p.ldb0 + p.k0 : (uint64_t)(p.k0 - 1) * p.ldb0 + p.n0;
         uint64_t ez = p.ta1 ? (uint64_t)(p.k1 - 1) * p.lda1 + p.m1 : (uint64_t)(p.m1 - 1) * p.lda1 + p.k1;
@@ -1520,6 +1525,10 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
         }
         if (g.lda < (g.ta ? g.m : g.k) || g.ldb < (g.tb ? g.k : g.n) || g.ldc < g.n) {
             err = id() + ": leading dimension smaller than row length";
+            return B2X_ERR_INVALID;
+        }
+        if (std::max(g.lda, std::max(g.ldb, g.ldc)) >= kMaxLeadingDim) { // (see compile_plan)
+            err = id() + ": leading dimension >= 2^22 elements is not supported";
             return B2X_ERR_INVALID;
         }
         uint64_t ea = g.ta ? (uint64_t)(g.k - 1) * g.lda + g.m : (uint64_t)(g.m - 1) * g.lda + g.k;

@@ -124,6 +124,8 @@ static const int kGGTileM = 128, kGGTileN = 128;
 static const int kGGCF = 2;
 static const int kGGRowUnit = 16; // tile heights are multiples of one MFMA row fragment
 static const int kGGNarrowFrags = 2, kGGNarrowN = 32; // 1-wave workgroups: tiles of up to kGGNarrowFrags row fragments x kGGNarrowN columns
+// largest leading dimension of any operand (elements): per-lane byte offsets inside a tile are 32-bit, products 24-bit
+static const int kMaxLeadingDim = 1 << 22;
 static const int kGGShortFrags = 3, kGGMidFrags = 5; // the short class holds tiles of up to 3 row fragments (4 waves/SIMD) or, for plans of
                                                       // mid-height sectors, up to 5 (3 waves/SIMD): CompiledPlan::short_frags // tiles of up to this many row fragments run on the low-register kernel instantiation
 

@@ -149,6 +149,12 @@ int b2x_plan_destroy(b2x_plan *p);
  * B2X_PLAN_CACHE_MB MiB of work lists (default 8192; 0 disables).  Counters since process start; clear() frees the cache. */
 int b2x_plan_cache_stats(uint64_t *hits, uint64_t *misses, uint64_t *plans, uint64_t *bytes);
 int b2x_plan_cache_clear(void);
+/* Idle device memory the library holds — the parked plans of the cache above and the pool of recycled scratch / slab buffers
+ * (B2X_POOL_MB, default a quarter of the card) — is given back to the driver: automatically whenever one of the library's
+ * own allocations fails (the allocation is then retried), and on request by b2x_trim, for other allocators of the same
+ * process (the counterpart of the reference returning a site's stack memory, src/core/allocator.hpp:175-214).
+ * bytes_released (may be NULL): growth of free device memory over the call. */
+int b2x_trim(uint64_t *bytes_released);
 
 /* single-GEMM lists (perturbative noise; partial multiplies) ------------------------------------------------
  * Replaces: the batch[1]-only lists that BatchGEMMSeq::multiply / three_rotate_tr_left / three_rotate_tr_right
