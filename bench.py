@@ -24,6 +24,17 @@ cached across steps).  `roofline.achieved` / `frac` are the HARDWARE roofline â€
 HIP-event time â€” and `roofline.algorithmic_tflops` is the same kernel time in the reference's flop count (it may exceed
 the MFMA peak, because that work is not executed).  `--keep-order 1` replays the reference's order pair by pair.
 
+Launch: `python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks ITSELF (child processes under
+torch.distributed.run, 127.0.0.1; decided before this process touches the GPU or imports torch) and fails â€” exit code 3,
+no JSON line â€” when fewer than N devices are visible: a one-GPU result is never printed under n_gpus = N.
+(`B2X_BENCH_SHARED_CARD=1` lets the ranks share cards, sigma summed through the host: a rehearsal of the data path for
+one-GPU boxes, marked `"rehearsal_shared_card": true`.)  The N > 1 line also carries `allreduce_ms` (HIP events around
+b2x_allreduce_sum), the per-rank kernel times and rooflines, and `ranks_seen` as the communicator reports them.
+`--emulate-ranks K` runs the K sum-MPO shards of the workload one after another on ONE GPU and prints per-shard time,
+MACs and operator bytes (load balance and how much of the shared-product saving survives the sharding) â€” a
+measurement of the shards, not a scaling curve.  `--sweep NAME` times whole DMRG sweeps of a committed chain (own leg,
+outside the H.psi timed region; see sweep_leg).
+
 Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events around the dominant kernel;
 `cpu_baseline` replays a bounded, deterministic sample of the same plan on the host cores, with the reference's own
 BatchGEMMSeq executor (oracle/_ref/ref_replay, kind "reference") when that binary travelled with the repo,
@@ -61,11 +72,99 @@ WORKLOADS = {
                         "Cr2/SVP SU2 mid-chain H.psi plan, uniform initial bond dimensions (reference capture M=250 sw1 site20) x16 -> M=4000"),
     "cr2_noocc_m1000": ("cr2_su2_m250_noocc_sw1_site20.struct.npz", 4, 1000,
                         "Cr2/SVP SU2 mid-chain H.psi plan, uniform initial bond dimensions (reference capture M=250 sw1 site20) x4 -> M=1000"),
+    # TRUE Cr2/SVP structures above the M=250 capture (fixed-M run of the reference from a random MPS, two Davidson iterations
+    # per site, occupation-guided initial bond dimensions, captured in sweep 1 at site 20 like the M=250 plan): what the
+    # "x f" workloads assume â€” pair count constant, sector populations proportional to M â€” is checked against these
+    "cr2_true_m1000": ("cr2_su2_m1000_sw1_site20.struct.npz", 1, 1000,
+                       "Cr2/SVP SU2 mid-chain H.psi plan, reference capture at its TRUE M=1000 (sw1 site20, fixed-M run)"),
+    "cr2_true_m2000": ("cr2_su2_m2000_sw1_site20.struct.npz", 1, 2000,
+                       "Cr2/SVP SU2 mid-chain H.psi plan, reference capture at its TRUE M=2000 (sw1 site20, fixed-M run)"),
+    "cr2_true_m4000": ("cr2_su2_m2000_sw1_site20.struct.npz", 2, 4000,
+                       "Cr2/SVP SU2 mid-chain H.psi plan, reference capture at TRUE M=2000 (sw1 site20) x2 -> M=4000"),
     "h10_m500": ("h10_sz_m500_sw1_site4.struct.npz", 1, 500,
                  "H10/STO-6G R=1.8 SZ mid-chain H.psi plan, reference capture at M=500 (sw1 site4)"),
     "hubbard_m3000": ("hubbard_l16_u4_sz_m3000_sw0_site7.struct.npz", 1, 3000,
                       "1D Hubbard L=16 U/t=4 SZ H.psi plan, reference capture at M=3000 (sw0 site7, fixed-M random MPS)"),
 }
+
+
+# committed event chains of reference runs (tests/golden/chain_*; block2-preview_amd/sweep.py replays them with every operator
+# resident in HBM): name -> (fixture prefix, symmetry, sweeps in the chain, what it is)
+SWEEP_CHAINS = {
+    "n2_m200": ("chain_n2su2/n2c", "su2", 2, "N2/STO-3G SU2 M=200 (BASELINE configs[0]), sweeps 0-1, no noise"),
+    "h10_m500": ("chain_h10sz/h10c", "sz", 2, "H10/STO-6G R=1.8 SZ M=500 (BASELINE configs[1]), sweeps 0-1, no noise"),
+    "hubbard_m500": ("chain_hubu2/hubc", "sz", 4, "1D Hubbard L=16 U/t=2 (bundled FCIDUMP) SZ M=500, sweeps 0-3, no noise"),
+    "cr2_m30": ("chain_cr2/cr2c", "su2", 2, "Cr2/SVP SU2 M=30, sweeps 0-1, no noise"),
+    "cr2_m250": ("chain_cr2_m250/cr2c250", "su2", 2, "Cr2/SVP SU2 M=250 (SURVEY 8d(i)), sweeps 0-1, no noise"),
+    "n2_noisy": ("chain_n2su2_noisy/n2n", "su2", 3, "N2/STO-3G SU2 M=200, noises 1e-5, 1e-5, 0 (perturbative noise on)"),
+    "h10_noisy": ("chain_h10sz_noisy/h10n", "sz", 3, "H10/STO-6G SZ M=500, noises 1e-5, 1e-5, 0 (perturbative noise on)"),
+}
+
+
+def sweep_leg(args):
+    """`--sweep NAME|all`: wall time of whole two-site DMRG sweeps on the device (sweep.DMRG over a committed event chain:
+    blocking, rotation, operator sums, H_eff plan + diagonal, device-resident Davidson, [perturbative noise,] density-matrix
+    split), per sweep, with the breakdown the reference prints (Teff / Teig / Tprt / Tblk / Tsplt, sweep_algorithm.hpp:
+    3208-3217) and, beside it, the reference's own clock for the same sweep as its generator logged it (SWEEP_TIME lines of
+    the fixture's log: 8 threads of the authoring container â€” a stated baseline, not the target).  One JSON line."""
+    from block2_preview_amd import capi
+    from block2_preview_amd.sweep import DMRG, ChainFixture
+
+    capi.device_init(0)
+    names = sorted(SWEEP_CHAINS) if args.sweep == "all" else [x for x in args.sweep.split(",") if x]
+    res = {}
+    for name in names:
+        if name not in SWEEP_CHAINS:
+            raise SystemExit("unknown chain %r (have: %s)" % (name, ", ".join(sorted(SWEEP_CHAINS))))
+        prefix, sym, n_sw, what = SWEEP_CHAINS[name]
+        path = os.path.join(GOLD, prefix)
+        if not (os.path.exists(path + ".log") or os.path.exists(path + ".zip")):
+            res[name] = {"error": "fixture %s not present" % prefix}
+            continue
+        for rep in range(2):  # the second pass finds every plan in the compiled-plan cache: a calculation at settled M
+            if rep == 0:
+                capi.plan_cache_clear()
+            fx = ChainFixture(path)
+            dm = DMRG(fx, sym)
+            t0 = time.perf_counter()
+            dm.init_environments()
+            capi.device_sync()
+            t_init = time.perf_counter() - t0
+            sweeps = []
+            for isw in range(n_sw):
+                before = dict(dm.tm)
+                nd0 = sum(dm.ndav.values())
+                t0 = time.perf_counter()
+                es = dm.sweep(isw, isw % 2 == 0)
+                capi.device_sync()
+                wall = time.perf_counter() - t0
+                tm = {k: round(dm.tm.get(k, 0.0) - before.get(k, 0.0), 4) for k in dm.tm if k != "site_total"}
+                worst = max(abs(dm.energies[k] - e) for k, e in fx.ref_energy.items() if k[0] == isw)
+                row = {"sweep": isw, "wall_s": round(wall, 4), "n_sites": len(es), "n_hpsi": sum(dm.ndav.values()) - nd0,
+                       "energy": min(es), "worst_site_dE_vs_reference": worst,
+                       # the reference's grouping: Teff = effective-Hamiltonian set-up, Teig = Davidson, Tprt = noise,
+                       # Tblk = blocking + rotation + operator sums (incl. the move to the next site), Tsplt = decomposition
+                       "Teff": round(tm.get("eff_ham.record", 0) + tm.get("eff_ham.device", 0), 4),
+                       "Teig": tm.get("eigs", 0.0),
+                       "Tprt": round(tm.get("noise.record", 0) + tm.get("noise.device", 0), 4),
+                       "Tblk": round(tm.get("block", 0) + tm.get("rotate", 0) + tm.get("transform", 0) + tm.get("assign", 0), 4),
+                       "Tsplt": tm.get("split", 0.0)}
+                rt = fx.ref_sweep_time.get(isw)
+                if rt:
+                    row["reference_cpu"] = {"wall_s": rt[0], "Teff": rt[1], "Teig": rt[2], "Tprt": rt[3], "Tblk": rt[4],
+                                            "Tsplt": rt[7], "threads": 8}
+                    row["speedup_vs_reference_cpu"] = round(rt[0] / wall, 3)
+                sweeps.append(row)
+            assert fx.pos == len(fx.events), "the chain was not replayed to its end"
+            key = name if rep == 0 else name + "_plans_cached"
+            res[key] = {"what": what + ("" if rep == 0 else " â€” second pass, every plan from the compiled-plan cache"),
+                        "init_environments_s": round(t_init, 4), "sweeps": sweeps, "final_energy": min(dm.energies.values()),
+                        "reference_final_energy": getattr(fx, "final_energy", None),
+                        "reference_total_time_s": fx.ref_total_time}
+            for t in list(dm.L.values()) + list(dm.R.values()):
+                t.close()
+    print(json.dumps({"mode": "sweep wall time (sweep.DMRG over committed reference event chains, one MI355X)",
+                      "chains": res}), flush=True)
 
 
 def parse():
@@ -88,7 +187,37 @@ def parse():
     ap.add_argument("--keep-order", type=int, default=0, help="1: always X.op(Y) first, as the reference (no per-pair reassociation)")
     ap.add_argument("--two-stage", type=int, default=0, help="0 auto, 1 all sectors through the grouped-GEMM path, -1 never")
     ap.add_argument("--scratch-mb", type=int, default=0, help="W scratch budget of the two-stage path (MiB, 0 = default)")
+    ap.add_argument("--emulate-ranks", type=int, default=0,
+                    help="K: run the K sum-MPO shards of the workload one after another on one GPU (per-shard table)")
+    ap.add_argument("--sweep", default="", help="time the sweeps of a committed chain: " + ", ".join(sorted(SWEEP_CHAINS)) + ", or all")
     return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started plainly (no RANK / WORLD_SIZE): start the N ranks as children of this process,
+    which has not imported torch or touched the GPU (never an exec of a process that initialised the device).  The
+    device count comes from a short-lived child as well."""
+    import socket
+
+    probe = subprocess.run([sys.executable, "-c", "from block2_preview_amd import capi; print(capi.device_count())"],
+                           cwd=ROOT, capture_output=True, text=True, timeout=600)
+    try:
+        ndev = int(probe.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        print("[bench] cannot count the devices: %s" % (probe.stderr[-500:],), file=sys.stderr)
+        sys.exit(3)
+    if ndev < args.gpus and os.environ.get("B2X_BENCH_SHARED_CARD") != "1":
+        print("[bench] --gpus %d asked for, %d device(s) visible: refusing to run (set B2X_BENCH_SHARED_CARD=1 for a "
+              "shared-card rehearsal of the data path)" % (args.gpus, ndev), file=sys.stderr)
+        sys.exit(3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    sys.exit(subprocess.run(cmd, cwd=ROOT).returncode)
 
 
 def sample_pairs(plan_pairs, budget_macs, max_op_bytes=12e9):
@@ -269,6 +398,119 @@ def site_step(scale, M, hpsi_ms, compile_s, dev, log):
     return out
 
 
+def fill_arena(arena_len, runs, dev):
+    """operator data of one rank's compact arena, generated on the device: an element is a function of its offset in the
+    UNSHARDED arena (a 64-bit multiplicative hash -> uniform [0,1)), so every decomposition computes the same H"""
+    import torch
+
+    arena_t = torch.empty(max(arena_len, 1), dtype=torch.float64, device=dev)
+    old_start = torch.from_numpy(np.ascontiguousarray(runs[0], np.int64)).to(dev)
+    new_start = torch.from_numpy(np.ascontiguousarray(runs[1], np.int64)).to(dev)
+    step = 1 << 27
+    for a in range(0, arena_len, step):
+        e = min(arena_len, a + step)
+        idx = torch.arange(a, e, dtype=torch.int64, device=dev)
+        r = torch.searchsorted(new_start, idx, right=True) - 1  # the run an element of the compact arena belongs to
+        gidx = old_start[r] + (idx - new_start[r])
+        h = gidx * 6364136223846793005 + 1442695040888963407  # (wraps mod 2^64)
+        arena_t[a:e] = ((h >> 11) & 0x1FFFFFFFFFFFFF).to(torch.float64) * (1.0 / 9007199254740992.0)
+        del idx, r, gidx, h
+    return arena_t
+
+
+def load_workload(args):
+    from block2_preview_amd import synth
+    from block2_preview_amd.planfile import read_struct_npz
+
+    sfile, scale, M, wname = WORKLOADS[args.workload]
+    if args.scale:
+        M, scale = M // scale * args.scale, args.scale
+        wname = "%s, sector dimensions x%d -> M=%d" % (sfile, scale, M)
+    if args.struct:
+        sfile, wname = args.struct, "pair plan %s x%d" % (os.path.basename(args.struct), scale)
+    base = read_struct_npz(sfile if os.path.isabs(sfile) else os.path.join(GOLD, sfile))
+    full = synth.scale_plan(base, scale) if scale != 1 else base
+    return full, scale, M, wname
+
+
+def emulate_ranks(args):
+    """The K shards of `synth.shard_pairs` (the sum-MPO split of bench.py --gpus K) one after another on ONE GPU: per-shard
+    H.psi time, executed and algorithmic MACs, operator bytes.  Pins, without a multi-GPU node, (i) the load balance of
+    the split and (ii) how much of the plan compiler's shared-product saving survives it; the sum of
+    the shards' sigma is checked against the unsharded plan.  NOT a scaling curve: no collective runs, nothing overlaps."""
+    import torch
+
+    from block2_preview_amd import capi, synth
+
+    K = args.emulate_ranks
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    capi.device_init(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    full, scale, M, wname = load_workload(args)
+    gp = torch.Generator(device=dev)
+    gp.manual_seed(7)
+    psi_t = torch.empty(full.psi_len, dtype=torch.float64, device=dev).uniform_(0.0, 1.0, generator=gp)
+    total = torch.zeros(full.sigma_len, dtype=torch.float64, device=dev)
+    rows = []
+    kw = dict(tile_n=args.tile_n, item_macs=args.item_macs, scratch_mb=args.scratch_mb, two_stage=args.two_stage,
+              tile_m=args.tile_m, keep_order=args.keep_order)
+
+    def run(pairs_r):
+        mine, arena_len, runs = synth.compact_arena(pairs_r, return_runs=True)
+        arena_t = fill_arena(arena_len, runs, dev)
+        arena = capi.Arena.adopt_device(arena_t.data_ptr(), arena_len, keep=arena_t)
+        t0 = time.time()
+        plan = capi.Plan(arena, mine, full.psi_len, full.sigma_len, **kw)
+        cs = time.time() - t0
+        st = plan.stats
+        sig = torch.zeros(full.sigma_len, dtype=torch.float64, device=dev)
+        for _ in range(max(1, args.warmup)):
+            plan.execute_device(psi_t.data_ptr(), sig.data_ptr(), 1.0, stream)
+        torch.cuda.synchronize()
+        sig.zero_()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            plan.execute_device(psi_t.data_ptr(), sig.data_ptr(), 1.0, stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / args.steps * 1e3
+        sig /= args.steps
+        tmp = torch.zeros_like(sig)
+        k_ms, _ = plan.time_kernel(psi_t.data_ptr(), tmp.data_ptr(), max(1, min(args.steps, 3)), stream)
+        del tmp
+        row = {"pairs": int(len(mine)), "operator_gb": round(arena_len * 8 / 1e9, 3), "hpsi_ms": round(ms, 3),
+               "kernel_ms": round(k_ms, 3), "gmac_algorithmic": round(st["macs"] / 1e9, 2),
+               "gmac_executed": round(st["macs_executed"] / 1e9, 2),
+               "executed_tflops": round(2.0 * st["macs_dominant"] / (k_ms * 1e-3) / 1e12, 2),
+               "plan_compile_ms": round(cs * 1e3, 1)}
+        plan.close(), arena.close()
+        capi.plan_cache_clear()
+        del arena_t
+        torch.cuda.empty_cache()
+        return row, sig
+
+    one, sig1 = run(full.pairs)
+    for r in range(K):
+        row, sig = run(synth.shard_pairs(full.pairs, r, K))
+        row["shard"] = r
+        rows.append(row)
+        total += sig
+        del sig
+    err = float((total - sig1).abs().max() / sig1.abs().max())
+    slow = max(r["hpsi_ms"] for r in rows)
+    out = {"mode": "emulate-ranks (shards run one after another on one GPU; not a scaling measurement)",
+           "workload": wname, "name": args.workload, "M": M, "K": K, "steps": args.steps,
+           "one_rank": one, "shards": rows,
+           "slowest_shard_ms": slow, "mean_shard_ms": round(float(np.mean([r["hpsi_ms"] for r in rows])), 3),
+           "balance_mean_over_max": round(float(np.mean([r["hpsi_ms"] for r in rows])) / slow, 4),
+           "ideal_speedup_without_allreduce": round(one["hpsi_ms"] / slow, 3),
+           "executed_macs_shards_over_one_rank": round(sum(r["gmac_executed"] for r in rows) / one["gmac_executed"], 4),
+           "operator_gb_shards_over_one_rank": round(sum(r["operator_gb"] for r in rows) / one["operator_gb"], 4),
+           "sum_of_shard_sigma_vs_one_rank_rel_err": err}
+    assert err < 1e-11, "the shards' partial sigma do not sum to the unsharded H.psi: %g" % err
+    print(json.dumps(out), flush=True)
+
+
 def traffic_of(workload):
     """HBM bytes per H.psi of this workload from the committed PMC passes (separate rocprofv3 --pmc runs, corrected as the
     micro-architecture guide prescribes; profiles/README.md).  The counters cannot be read from inside a timed run, so the
@@ -288,22 +530,31 @@ def main():
         import faulthandler
 
         faulthandler.dump_traceback_later(int(os.environ["B2X_BENCH_WATCHDOG"]), exit=True)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)  # does not return
+    if args.sweep:
+        return sweep_leg(args)
+    if args.emulate_ranks:
+        return emulate_ranks(args)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("launch with --nproc-per-node equal to --gpus")
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE = %d but --gpus %d: launch with --nproc-per-node equal to --gpus" % (world, args.gpus))
     log = (lambda *a: print("[bench]", *a, file=sys.stderr, flush=True)) if rank == 0 else (lambda *a: None)
     ndev = torch.cuda.device_count()
-    # rehearsal of the N>1 path on a box with fewer cards than ranks: the ranks share cards (every rank decides alike)
+    # rehearsal of the N>1 path on a box with fewer cards than ranks (B2X_BENCH_SHARED_CARD=1 only): the ranks share cards
     shared_card = world > 1 and int(os.environ.get("LOCAL_WORLD_SIZE", world)) > ndev
+    if shared_card and os.environ.get("B2X_BENCH_SHARED_CARD") != "1":
+        raise SystemExit("bench.py: %d ranks on this node but %d device(s) visible â€” refusing to run (a result on fewer "
+                         "cards than ranks is not an n_gpus = %d measurement; B2X_BENCH_SHARED_CARD=1 rehearses the data "
+                         "path on shared cards)" % (int(os.environ.get("LOCAL_WORLD_SIZE", world)), ndev, world))
     local = local % max(ndev, 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from block2_preview_amd import capi, synth
-    from block2_preview_amd.planfile import read_struct_npz
 
     capi.device_init(local)
     comm, comm_kind = None, "none"
@@ -315,8 +566,10 @@ def main():
         if not shared_card and os.environ.get("B2X_BENCH_COMM", "b2x") == "b2x":
             id_file = os.path.join(tempfile.gettempdir(), "b2x_rccl_id_%s_%s" % (
                 os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RUN_ID", "0")))
+            nonce_t = torch.tensor([int.from_bytes(os.urandom(7), "little") | 1], dtype=torch.int64)
+            dist.broadcast(nonce_t, 0)  # one session nonce per launch: a file left by an earlier run is rejected
             try:
-                comm = capi.Comm(rank, world, id_file=id_file)
+                comm = capi.Comm(rank, world, id_file=id_file, nonce=int(nonce_t.item()))
                 comm_kind = "b2x_allreduce_sum (RCCL through the C ABI)"
             except capi.B2XError as e:
                 log("b2x_comm_init failed (%s)" % e)
@@ -330,32 +583,14 @@ def main():
         else:
             comm_kind = "gloo via host (rehearsal: ranks share one card, RCCL refuses that)"
     t0 = time.time()
-    sfile, scale, M, wname = WORKLOADS[args.workload]
-    if args.scale:
-        M, scale = M // scale * args.scale, args.scale
-        wname = "%s, sector dimensions x%d -> M=%d" % (sfile, scale, M)
-    if args.struct:
-        sfile, wname = args.struct, "pair plan %s x%d" % (os.path.basename(args.struct), scale)
-    base = read_struct_npz(sfile if os.path.isabs(sfile) else os.path.join(GOLD, sfile))
-    full = synth.scale_plan(base, scale) if scale != 1 else base
+    full, scale, M, wname = load_workload(args)
     mine, arena_len, runs = synth.compact_arena(synth.shard_pairs(full.pairs, rank, world), return_runs=True)
     log("plan: %d pairs (%d on rank 0), %.3f TMAC, psi %d, operators %.2f GB on rank 0, M=%d" % (
         len(full.pairs), len(mine), full.macs / 1e12, full.psi_len, arena_len * 8 / 1e9, M))
     # synthetic data generated on the device: uniform [0,1) like Random::fill (src/core/utils.hpp:247-252).  An operator
     # element is a function of its offset in the UNSHARDED arena (a 64-bit multiplicative hash), so a rank's blocks hold the
     # same numbers in every decomposition and the summed sigma of N ranks equals the one-rank sigma
-    arena_t = torch.empty(max(arena_len, 1), dtype=torch.float64, device=dev)
-    old_start = torch.from_numpy(np.ascontiguousarray(runs[0], np.int64)).to(dev)
-    new_start = torch.from_numpy(np.ascontiguousarray(runs[1], np.int64)).to(dev)
-    step = 1 << 27
-    for a in range(0, arena_len, step):
-        e = min(arena_len, a + step)
-        idx = torch.arange(a, e, dtype=torch.int64, device=dev)
-        r = torch.searchsorted(new_start, idx, right=True) - 1  # the run an element of the compact arena belongs to
-        gidx = old_start[r] + (idx - new_start[r])
-        h = gidx * 6364136223846793005 + 1442695040888963407  # (wraps mod 2^64)
-        arena_t[a:e] = ((h >> 11) & 0x1FFFFFFFFFFFFF).to(torch.float64) * (1.0 / 9007199254740992.0)
-        del idx, r, gidx, h
+    arena_t = fill_arena(arena_len, runs, dev)
     gp = torch.Generator(device=dev)
     gp.manual_seed(7)
     psi_t = torch.empty(full.psi_len, dtype=torch.float64, device=dev).uniform_(0.0, 1.0, generator=gp)
@@ -394,7 +629,7 @@ def main():
     for _ in range(args.steps):
         one_step()
     fence()
-    dt = time.perf_counter() - t0
+    dt = dt_local = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -402,6 +637,30 @@ def main():
     checksum = float(sigma_t.sum().item())
     # roofline of the dominant kernel on this rank: HIP events on the launch stream
     k_ms, tot_ms = plan.time_kernel(psi_t.data_ptr(), sigma_t.data_ptr(), max(1, min(args.steps, 3)), stream)
+    per_rank = None
+    if world > 1:
+        # the all-reduce of sigma on its own: HIP events on the caller's stream around b2x_allreduce_sum (the collective runs
+        # on the communicator's stream, forked from / joined to this one), every repetition entered together
+        ar = []
+        if comm is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(max(3, min(args.steps, 10))):
+                fence()
+                ev0.record()
+                comm.allreduce_sum(sigma_t.data_ptr(), full.sigma_len, stream)
+                ev1.record()
+                torch.cuda.synchronize()
+                ar.append(ev0.elapsed_time(ev1))
+        me = {"rank": rank, "comm_rank_size": list(comm.rank_size()) if comm is not None else None,
+              "device": local, "pairs": int(len(mine)), "operator_gb": round(arena_len * 8 / 1e9, 3),
+              "macs_algorithmic": int(st["macs"]), "macs_executed": int(st["macs_executed"]),
+              "kernel_ms": round(k_ms, 3), "hpsi_ms": round(tot_ms, 3), "step_ms": round(dt_local / args.steps * 1e3, 3),
+              "executed_tflops": round(2.0 * st["macs_dominant"] / (k_ms * 1e-3) / 1e12, 3),
+              "frac": round(2.0 * st["macs_dominant"] / (k_ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS, 4),
+              "allreduce_ms": round(float(np.mean(ar)), 4) if ar else None,
+              "allreduce_ms_min": round(float(np.min(ar)), 4) if ar else None}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, me)
     if rank == 0:
         traffic, traffic_source = traffic_of(args.workload) if world == 1 and not args.scale and not args.struct else (None, None)
         flops_step = 2.0 * full.macs
@@ -434,6 +693,21 @@ def main():
                          "atomic_fallback": st["fallback"]},
             "sigma_checksum": checksum,
         }
+        if per_rank is not None:
+            # the N > 1 line: what every rank measured (the headline `value` is total flops / the slowest rank's wall time)
+            kms = [r["kernel_ms"] for r in per_rank]
+            ars = [r["allreduce_ms"] for r in per_rank if r["allreduce_ms"] is not None]
+            out["ranks_seen"] = sorted(r["comm_rank_size"][0] if r["comm_rank_size"] else r["rank"] for r in per_rank)
+            out["comm_size_seen"] = sorted(set(r["comm_rank_size"][1] for r in per_rank if r["comm_rank_size"])) or None
+            out["allreduce_ms"] = round(max(ars), 4) if ars else None
+            out["allreduce_bytes"] = int(full.sigma_len) * 8
+            out["kernel_ms_min_max"] = [min(kms), max(kms)]
+            out["roofline_frac_min_max"] = [min(r["frac"] for r in per_rank), max(r["frac"] for r in per_rank)]
+            out["executed_macs_all_ranks_over_one_rank_algorithmic"] = round(
+                sum(r["macs_executed"] for r in per_rank) / max(1, int(full.macs)), 4)
+            out["per_rank"] = per_rank
+            out["rehearsal_shared_card"] = bool(shared_card)
+            assert out["ranks_seen"] == list(range(world)), "not every rank reported"
         want_site = args.site_step == 1 or (args.site_step < 0 and world == 1 and args.workload.startswith("cr2_")
                                             and "noocc" not in args.workload and not args.scale and not args.struct)
         if want_site:

@@ -25,7 +25,7 @@ DECLARED_SYMBOLS = [
     "b2x_gemm_plan_create", "b2x_outer_build",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
     "b2x_vec_multi_dot", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
-    "b2x_comm_init", "b2x_comm_unique_id", "b2x_comm_init_id", "b2x_comm_rank", "b2x_allreduce_sum", "b2x_broadcast",
+    "b2x_comm_init", "b2x_comm_init_session", "b2x_comm_unique_id", "b2x_comm_init_id", "b2x_comm_rank", "b2x_allreduce_sum", "b2x_broadcast",
     "b2x_barrier", "b2x_comm_destroy",
 ]
 
@@ -34,7 +34,8 @@ class PlanStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "n_pairs", "macs", "op_elems_unique", "psi_len", "sigma_len", "n_targets", "n_tiles", "n_items",
         "n_parts", "device_bytes", "macs_executed", "dominant_class", "macs_dominant",
-        "macs_alg_dominant", "n_launches", "macs_issued", "fallback", "n_staged")]
+        "macs_alg_dominant", "n_launches", "macs_issued", "fallback", "n_staged", "n_flipped", "n_shared_products",
+        "n_merged_groups", "n_merged_members")]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n, _ in self._fields_}
@@ -285,11 +286,14 @@ class Comm:
     """RCCL communicator of the sum-MPO path (ParallelCommunicator<S> of the reference: allreduce_sum / broadcast /
     barrier on device-resident fp64 vectors).  One process per GPU; call device_init() first."""
 
-    def __init__(self, rank, size, id_file=None, id_bytes=None):
+    def __init__(self, rank, size, id_file=None, id_bytes=None, nonce=0):
         h = C.c_void_p()
         if id_bytes is not None:
             buf = C.create_string_buffer(bytes(id_bytes), 128)
             check(lib().b2x_comm_init_id(C.byref(h), C.c_int(rank), C.c_int(size), buf))
+        elif nonce:
+            check(lib().b2x_comm_init_session(C.byref(h), C.c_int(rank), C.c_int(size),
+                                              None if id_file is None else os.fsencode(id_file), C.c_uint64(int(nonce))))
         else:
             check(lib().b2x_comm_init(C.byref(h), C.c_int(rank), C.c_int(size),
                                       None if id_file is None else os.fsencode(id_file)))
@@ -300,6 +304,12 @@ class Comm:
         buf = C.create_string_buffer(128)
         check(lib().b2x_comm_unique_id(buf))
         return buf.raw
+
+    def rank_size(self):
+        """(rank, size) as the communicator itself reports them (b2x_comm_rank)"""
+        r, n = C.c_int(-1), C.c_int(-1)
+        check(lib().b2x_comm_rank(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
 
     def allreduce_sum(self, dev_ptr, n, stream=0):
         check(lib().b2x_allreduce_sum(self._h, C.c_void_p(int(dev_ptr)), C.c_size_t(n), C.c_void_p(int(stream))))

@@ -8,7 +8,9 @@
 // see (single node: any local directory), the others wait for it.  RCCL is loaded on first use (dlopen), so a serial
 // run never maps it and a process that already carries an RCCL (PyTorch) shares that copy.
 #include "../../include/b2x.h"
+#include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
@@ -129,8 +131,16 @@ int b2x_comm_init_id(b2x_comm **out, int rank, int size, const void *id128) {
         e = hipMalloc((void **)&c->token, sizeof(double));
     if (e == hipSuccess)
         e = hipMemset(c->token, 0, sizeof(double));
-    if (e != hipSuccess) {
+    if (e != hipSuccess) { // give back whatever was created before the failing step
         (void)g_rccl.CommDestroy(c->comm);
+        if (c->token)
+            (void)hipFree(c->token);
+        if (c->done)
+            (void)hipEventDestroy(c->done);
+        if (c->ready)
+            (void)hipEventDestroy(c->ready);
+        if (c->stream)
+            (void)hipStreamDestroy(c->stream);
         delete c;
         return b2x_set_error(B2X_ERR_DEVICE, std::string("b2x_comm_init: ") + hipGetErrorString(e));
     }
@@ -138,19 +148,34 @@ int b2x_comm_init_id(b2x_comm **out, int rank, int size, const void *id128) {
     return B2X_OK;
 }
 
-int b2x_comm_init(b2x_comm **out, int rank, int size, const char *id_file) {
+// File rendezvous.  The file is self-identifying: magic, the caller's session nonce, the 128-byte id.  Rank 0 removes
+// whatever is at `id_file` (a file left by a crashed earlier run), writes a private file and renames it into place; the
+// other ranks poll and accept only a complete file that carries THEIR nonce — a stale file of another session is ignored
+// until the timeout (B2X_COMM_TIMEOUT_S, default 120 s) and then reported as such.  Rank 0 removes the file again once
+// the communicator exists (ncclCommInitRank returns when every rank has joined).  nonce 0 = "any session": safe only
+// when the caller guarantees that no file of an earlier run can be at that path.
+static const char kIdMagic[8] = {'B', '2', 'X', 'I', 'D', '0', '0', '1'};
+struct IdFile {
+    char magic[8];
+    uint64_t nonce;
+    char id[128];
+};
+
+int b2x_comm_init_session(b2x_comm **out, int rank, int size, const char *id_file, uint64_t nonce) {
     if (!out || size < 1 || rank < 0 || rank >= size || (size > 1 && (!id_file || !id_file[0])))
         return b2x_set_error(B2X_ERR_INVALID, "b2x_comm_init: bad rank / size / id_file");
-    char id[128];
+    IdFile rec;
+    memcpy(rec.magic, kIdMagic, 8), rec.nonce = nonce;
     if (size == 1 || rank == 0) {
-        int rc = b2x_comm_unique_id(id);
+        int rc = b2x_comm_unique_id(rec.id);
         if (rc != B2X_OK)
             return rc;
     }
-    if (size > 1 && rank == 0) { // publish: write a private file, then rename it into place (readers never see a partial id)
+    if (size > 1 && rank == 0) {
+        (void)unlink(id_file); // a leftover of an earlier run must not be taken for this session's id
         const std::string tmp = std::string(id_file) + ".tmp." + std::to_string((long)getpid());
         FILE *f = fopen(tmp.c_str(), "wb");
-        if (!f || fwrite(id, 1, sizeof(id), f) != sizeof(id)) {
+        if (!f || fwrite(&rec, 1, sizeof(rec), f) != sizeof(rec)) {
             if (f)
                 fclose(f);
             return b2x_set_error(B2X_ERR_STATE, "b2x_comm_init: cannot write " + tmp);
@@ -159,20 +184,36 @@ int b2x_comm_init(b2x_comm **out, int rank, int size, const char *id_file) {
         if (rename(tmp.c_str(), id_file) != 0)
             return b2x_set_error(B2X_ERR_STATE, std::string("b2x_comm_init: cannot publish ") + id_file);
     } else if (size > 1) {
-        bool got = false;
-        for (int tries = 0; tries < 1200 && !got; tries++) { // up to 120 s
+        const char *te = getenv("B2X_COMM_TIMEOUT_S");
+        const int tries_max = (te ? std::max(1, atoi(te)) : 120) * 10;
+        bool got = false, stale = false;
+        for (int tries = 0; tries < tries_max && !got; tries++) {
             FILE *f = fopen(id_file, "rb");
             if (f) {
-                got = fread(id, 1, sizeof(id), f) == sizeof(id);
+                IdFile r;
+                // (rank 0 renames a complete file into place: a short or foreign file is never this session's)
+                if (fread(&r, 1, sizeof(r), f) == sizeof(r) && memcmp(r.magic, kIdMagic, 8) == 0 &&
+                    (nonce == 0 || r.nonce == nonce))
+                    rec = r, got = true;
+                else
+                    stale = true;
                 fclose(f);
             }
             if (!got)
                 std::this_thread::sleep_for(std::chrono::milliseconds(100));
         }
         if (!got)
-            return b2x_set_error(B2X_ERR_STATE, std::string("b2x_comm_init: no id from rank 0 in ") + id_file);
+            return b2x_set_error(B2X_ERR_STATE, std::string("b2x_comm_init: no id of this session from rank 0 in ") + id_file +
+                                                    (stale ? " (a file of another session is there: stale id rejected)" : ""));
     }
-    return b2x_comm_init_id(out, rank, size, id);
+    int rc = b2x_comm_init_id(out, rank, size, rec.id);
+    if (size > 1 && rank == 0)
+        (void)unlink(id_file); // every rank has joined (or the attempt failed): the id is spent either way
+    return rc;
+}
+
+int b2x_comm_init(b2x_comm **out, int rank, int size, const char *id_file) {
+    return b2x_comm_init_session(out, rank, size, id_file, 0);
 }
 
 int b2x_comm_rank(const b2x_comm *c, int *rank, int *size) {

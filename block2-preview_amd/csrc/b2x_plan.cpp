@@ -939,6 +939,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                                     merged_skip[mk[x].q - i] = 1;
                             }
                             merged_off[mk[a].q - i] = s_off;
+                            out.stats.n_merged_groups++, out.stats.n_merged_members += gsz;
                             OWork wk{};
                             wk.out_off = s_off, wk.ld = -scols, wk.rows = srows, wk.cols = scols; // ld < 0: assign
                             wk.rpt = 16; // outer_build_k<16>
@@ -1455,7 +1456,9 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             const Cand &cd = cand[q];
             const b2x_pair &p = ep[win[cd.wi].pair];
             const bool same = allow_flip && q > 0 && !cur.empty() && !key_less(cand[q - 1], cd) && !key_less(cd, cand[q - 1]);
+            out.stats.n_flipped += cd.flip ? 1 : 0;
             if (same) { // shares the product of the previous pair (still in this super-step)
+                out.stats.n_shared_products++;
                 cur.push_back(PW{cd.c, cd.wi, last_off, cd.flip, false});
                 continue;
             }

@@ -51,6 +51,7 @@ class ChainFixture:
                 self.events.append((int(m.group(1)), m.group(2), fn))
         self.events.sort()
         self.ref_energy, self.meta = {}, {}
+        self.ref_spectra, self.ref_sweep_time, self.ref_total_time = {}, {}, None
         for line in open(prefix + ".log"):
             t = line.split()
             if t and t[0] == "SITE_ENERGY":
@@ -59,6 +60,12 @@ class ChainFixture:
                 self.meta[int(t[1])] = (t[2], int(t[3]), int(t[4]))
             elif t and t[0] == "FINAL_ENERGY":
                 self.final_energy = float(t[1])
+            elif t and t[0] == "SPECTRA":  # sqrt of every density-matrix eigenvalue the reference truncated at this site
+                self.ref_spectra[(int(t[1]), int(t[2]))] = (float(t[3]), np.array([float(x) for x in t[5:]]))
+            elif t and t[0] == "SWEEP_TIME":  # the reference's own clock: wall, teff, teig, tprt, tblk, tmve, tdm, tsplt, ...
+                self.ref_sweep_time[int(t[1])] = [float(x) for x in t[2:]]
+            elif t and t[0] == "TOTAL_TIME":
+                self.ref_total_time = float(t[1])
         self.pos = 0
 
     def next(self, *kinds):
@@ -120,6 +127,10 @@ class DMRG:
         self.energies, self.tm, self.n_sites = {}, Timers(), None
         self.ndav = {}
         self.n_zero_ops, self.zero_log = 0, []
+        self.pket = None                 # perturbed wavefunctions of the last solved site (noisy sweeps)
+        self.check_truncation = False    # True: every split also makes its OWN choice of kept states and logs where it
+        self.trunc_log = {}              # differs from the fixture's bond dimensions (see _split)
+        self.site_key = None
 
     # ---- steps ------------------------------------------------------------------------------------------------
     def _assign(self, d):
@@ -283,7 +294,36 @@ class DMRG:
         return {"plan": plan, "arena": arena, "arena_t": arena_t, "diag": diag, "kinfo": kinfo, "n": n,
                 "const_e": float(d["const_e"][0]), "n_pairs": len(pairs)}
 
-    def _solve(self, parts):
+    def _perturb(self, d, part, ket):
+        """EffectiveHamiltonian::perturbative_noise (src/dmrg/effective_hamiltonian.hpp:252-423) on the device: the symbolic
+        walk records the single-GEMM list (host mirror, from the fixture's sub-labels and perturbed-ket infos), the list runs
+        on the grouped-GEMM kernel over the SAME operator arena as H.psi (b2x_gemm_plan_create), the perturbed
+        wavefunctions come back to the host for the density matrix.  d = the site's `enoise` event."""
+        from .planfile import GEMM_DTYPE
+
+        t0 = time.perf_counter()
+        al, n = int(d["arena.len"][0]), part["n"]
+        assert al == part["arena_t"].n, "the noise step of a site shares the operator arena of its effective Hamiltonian"
+        dd = dict(d)
+        dd["arena"], dd["psi"] = np.zeros(al), np.zeros(n)
+        h = self.host.SymbolicEffectiveHamiltonian(self.sym, dd)
+        gb, _ = h.perturbative_noise(dd, False)
+        gemms = np.frombuffer(bytes(gb), GEMM_DTYPE)
+        out_len = int(d["noise.args"][5])
+        self.tm.add("noise.record", t0)
+        t0 = time.perf_counter()
+        gp = capi.GemmPlan(part["arena"], gemms, n, out_len)
+        out = capi.DeviceBuffer(out_len)
+        gp.execute_device(ket.ptr, out.ptr, 1.0)
+        capi.device_sync()
+        pk = out.download()
+        gp.close(), out.close()
+        infos = [_info(d, i) for i in d["noise.vinfo"]]
+        self.tm.add("noise.device", t0)
+        return {"data": pk, "infos": infos, "offs": [int(o) for o in d["noise.voff"]], "noise": float(d["noise.value"][0]),
+                "n_gemms": len(gemms)}
+
+    def _solve(self, parts, noise_event=None):
         """Davidson on the device over H = sum of the parts' plans (one part: the serial case; several: the sum-MPO
         Hamiltonian H = sum_r H_r with every H_r psi accumulated into the same sigma — on separate GPUs that sum is the
         all-reduce of ParallelTensorFunctions::operator()).  The diagonals of the parts are summed likewise."""
@@ -326,56 +366,142 @@ class DMRG:
             sig.close()
         const_e = parts[0]["const_e"]  # (every rank's fixture carries the SAME constant: it is added once, by the root)
         self.const_e = const_e
+        self.pket = None
+        if noise_event is not None:
+            if len(parts) != 1:
+                raise NotImplementedError("perturbative noise of a sum-MPO site (the reduce of the perturbed kets to the root)")
+            self.pket = self._perturb(noise_event, parts[0], ket)
         for q in parts:
             q["plan"].close(), q["arena"].close(), q["arena_t"].close(), q["diag"].close()
         ket.close()
         return e + const_e, ndav, psi, p0["kinfo"], sum(q["n_pairs"] for q in parts)
 
-    def _eigs(self, d):
-        return self._solve([self._eff_ham(d)])
+    def _eigs(self, d, noise_event=None):
+        return self._solve([self._eff_ham(d)], noise_event)
+
+    def _bond_labels(self, info, right):
+        """(n, 2S or 2Sz, pg) of the bond index of every block of a two-site wavefunction: its right label when the
+        right bond is kept, else its left one (src/core/symmetry.hpp:654-731, 1183-1306)"""
+        n, tl, tw, pg = _fields(info["q"])
+        dn, _, dtw, dpg = _fields(np.array([info["dq"]], np.uint64))
+        if self.sym == "sz":
+            # SZ: 2Sz is a SIGNED 16-bit field and adds like n; the stored label of a psi block is its (negated) right
+            # label, the left one is label + dq
+            sgn = lambda t: np.where(t >= 32768, t - 65536, t)
+            tw, dtw = sgn(tw), sgn(dtw)
+            return (-n, -tw, pg) if right else (n + dn[0], tw + dtw[0], pg ^ dpg[0])
+        if right:      # SU2, right label of a psi block: -ket  ->  (-n, twos, pg)
+            return -n, tw, pg
+        return n + dn[0], tl, pg ^ dpg[0]  # left label: get_bra(dq)  ->  (n + dq.n, twos_low, pg ^ dq.pg)
+
+    def _density_blocks(self, right):
+        """the wavefunctions whose density matrices are summed at this bond: psi and, on a noisy sweep, the perturbed
+        wavefunctions scaled as MovingEnvironment::scale_perturbative_noise does (src/dmrg/moving_environment.hpp:3655-3671:
+        every matrix normalised, then the group scaled to norm sqrt(noise)); density_matrix() adds the matrices 1.. of the
+        group, not matrix 0 (:3530-3536).  Returns [(data, info, labels)]"""
+        psi, kinfo = self.psi
+        out = [(psi, kinfo, self._bond_labels(kinfo, right))]
+        if self.pket is not None and self.pket["noise"] != 0:
+            pk, tiny = self.pket, 1e-20
+            mats = []
+            for inf, off in zip(pk["infos"], pk["offs"]):
+                m = pk["data"][off:off + inf["len"]].copy()
+                nm = np.linalg.norm(m)
+                if abs(nm) > tiny:
+                    m /= nm
+                mats.append(m)
+            tot = np.sqrt(sum(float(m @ m) for m in mats))
+            if abs(tot) > tiny:
+                mats = [m * (np.sqrt(pk["noise"]) / tot) for m in mats]
+            for j in range(1, len(mats)):
+                out.append((mats[j], pk["infos"][j], self._bond_labels(pk["infos"][j], right)))
+        return out
 
     def _split(self, d, right):
         """new MPS tensor = the dominant eigenvectors of the density matrix of psi (DensityMatrix decomposition,
-        src/dmrg/moving_environment.hpp density_matrix / split_density_matrix), per quantum-number sector of the bond,
-        kept-state counts as in the fixture's tensor info (the bond dimension bookkeeping is block2's)"""
+        src/dmrg/moving_environment.hpp density_matrix :3512-3538 / split_density_matrix :4218-), per quantum-number sector
+        of the bond, kept-state counts as in the fixture's tensor info (the bond dimension bookkeeping is block2's).
+        With check_truncation the step also makes block2's choice itself — all eigenvalues of all sectors sorted, the
+        largest k kept (truncate_density_matrix, :3674-3800, TruncationTypes::Physical) — and logs, per site, whether its
+        per-sector counts equal the fixture's and how far the last kept weight is from the first discarded one."""
         t0 = time.perf_counter()
-        psi, kinfo = self.psi
         ainfo = _info(d, d["mps.info"][0])
         out = np.zeros(int(d["meta"][7]))
         base = int(d["mps.off"][0])
-        n, tl, tw, pg = _fields(kinfo["q"])
-        dn, _, dtw, dpg = _fields(np.array([kinfo["dq"]], np.uint64))
         an, _, atw, apg = _fields(ainfo["q"])
         if self.sym == "sz":
-            # SZ (src/core/symmetry.hpp:654-731): 2Sz is a SIGNED 16-bit field and adds like n; the stored label of a psi
-            # block is its (negated) right label, the left one is label + dq
-            sgn = lambda t: np.where(t >= 32768, t - 65536, t)
-            tw, dtw, atw = sgn(tw), sgn(dtw), sgn(atw)
-            if right:
-                bn, btw, bpg = -n, -tw, pg
-            else:
-                bn, btw, bpg = n + dn[0], tw + dtw[0], pg ^ dpg[0]
-        elif right:  # SU2: right label of a psi block: -ket  ->  (-n, twos, pg)
-            bn, btw, bpg = -n, tw, pg
-        else:        # left label: get_bra(dq)  ->  (n + dq.n, twos_low, pg ^ dq.pg)
-            bn, btw, bpg = n + dn[0], tl, pg ^ dpg[0]
+            atw = np.where(atw >= 32768, atw - 65536, atw)
+        srcs = self._density_blocks(right)
+
+        def rho_of(key, fused):
+            rho = np.zeros((fused, fused))
+            for data, inf, (bn, btw, bpg) in srcs:
+                for i in np.nonzero((bn == key[0]) & (btw == key[1]) & (bpg == key[2]))[0]:
+                    b = data[inf["ntot"][i]:inf["ntot"][i] + inf["nbra"][i] * inf["nket"][i]].reshape(
+                        int(inf["nbra"][i]), int(inf["nket"][i]))
+                    assert (b.shape[1] if right else b.shape[0]) == fused
+                    rho += b.T @ b if right else b @ b.T
+            return rho
+
+        kept_of, spectrum = {}, {}
         for s in range(len(ainfo["q"])):
-            sel = np.nonzero((bn == an[s]) & (btw == atw[s]) & (bpg == apg[s]))[0]
+            key = (int(an[s]), int(atw[s]), int(apg[s]))
             rows, cols = int(ainfo["nbra"][s]), int(ainfo["nket"][s])
             fused, kept = (cols, rows) if right else (rows, cols)
-            blocks = [psi[kinfo["ntot"][i]:kinfo["ntot"][i] + kinfo["nbra"][i] * kinfo["nket"][i]].reshape(
-                int(kinfo["nbra"][i]), int(kinfo["nket"][i])) for i in sel]
-            rho = np.zeros((fused, fused))
-            for b in blocks:
-                assert (b.shape[1] if right else b.shape[0]) == fused
-                rho += b.T @ b if right else b @ b.T
-            w, u = np.linalg.eigh(rho)
+            w, u = np.linalg.eigh(rho_of(key, fused))
+            kept_of[key], spectrum[key] = kept, w[::-1]
             u = u[:, ::-1][:, :kept]  # largest weights first
             blk = u.T if right else u
             o = base + int(ainfo["ntot"][s])
             out[o:o + rows * cols] = blk.reshape(-1)
+        if self.check_truncation:
+            self._check_truncation(right, kept_of, spectrum, rho_of)
         self.tm.add("split", t0)
         return out
+
+    def _check_truncation(self, right, kept_of, spectrum, rho_of):
+        """this loop's own global choice of the kept states against the bond dimensions of the fixture (see _split)"""
+        psi, kinfo = self.psi
+        bn, btw, bpg = self._bond_labels(kinfo, right)
+        fdim = kinfo["nket"] if right else kinfo["nbra"]
+        for i in range(len(bn)):  # sectors of the density matrix the reference kept nothing of
+            key = (int(bn[i]), int(btw[i]), int(bpg[i]))
+            if key not in spectrum:
+                spectrum[key] = np.linalg.eigvalsh(rho_of(key, int(fdim[i])))[::-1]
+                kept_of[key] = 0
+        keys = sorted(spectrum)
+        allw = np.concatenate([spectrum[k] for k in keys])
+        owner = np.concatenate([np.full(len(spectrum[k]), j) for j, k in enumerate(keys)])
+        k_tot = int(sum(kept_of.values()))
+        order = np.argsort(-allw, kind="stable")
+        mine = np.bincount(owner[order[:k_tot]], minlength=len(keys))
+        theirs = np.array([kept_of[k] for k in keys])
+        last_kept = float(allw[order[k_tot - 1]]) if k_tot else 0.0
+        first_out = float(allw[order[k_tot]]) if k_tot < len(allw) else 0.0
+        rec = {"k": k_tot, "n_states": int(len(allw)), "same_counts": bool((mine == theirs).all()),
+               "last_kept": last_kept, "first_discarded": first_out, "w_max": float(allw.max()),
+               "discarded_weight": float(np.clip(allw[order[k_tot:]], 0, None).sum()), "mismatch": []}
+        if not rec["same_counts"]:
+            # every state on which the two choices differ lies between the smallest weight the FIXTURE keeps and the largest
+            # it discards; for a tie (a degenerate band at the cut) that interval is tiny relative to w_max
+            lo, hi = np.inf, -np.inf
+            for j, kk in enumerate(keys):
+                w = spectrum[kk]
+                if theirs[j] != mine[j]:
+                    a, b = sorted((int(theirs[j]), int(mine[j])))
+                    lo, hi = min(lo, float(w[a:b].min())), max(hi, float(w[a:b].max()))
+                    rec["mismatch"].append((kk, int(theirs[j]), int(mine[j])))
+            rec["band"] = (lo, hi)
+            rec["band_rel_width"] = (hi - lo) / rec["w_max"]
+        ref = self.fx.ref_spectra.get(self.site_key)
+        if ref is not None:  # the reference's spectrum of this bond: singular values of every sector before the cut
+            rw = np.sort(ref[1] ** 2)[::-1]
+            mw = np.sort(np.clip(allw, 0, None))[::-1]
+            m = min(len(rw), len(mw))
+            rec["ref_discarded_weight"] = ref[0]
+            rec["spectrum_max_abs_diff"] = float(np.abs(rw[:m] - mw[:m]).max()) if m else 0.0
+            rec["n_states_ref"] = int(len(rw))
+        self.trunc_log[self.site_key] = rec
 
     # ---- the loop ---------------------------------------------------------------------------------------------
     def init_environments(self):
@@ -405,7 +531,11 @@ class DMRG:
             t_site = time.perf_counter()
             self._move_to(i, forward)
             d = self._eham_event(isw, i)
-            e, ndav, psi, kinfo, n_pairs = self._eigs(d)
+            dn = None
+            if fx.peek() == "enoise":  # a noisy sweep of the reference: the perturbative-noise step follows the solve
+                dn = fx.next("enoise")[1]
+                assert (int(dn["chain.meta"][0]), int(dn["chain.meta"][1])) == (isw, i)
+            e, ndav, psi, kinfo, n_pairs = self._eigs(d, dn)
             self._finish_site(isw, i, e, ndav, psi, kinfo)
             out.append(e)
             self.tm.add("site_total", t_site)
@@ -418,6 +548,7 @@ class DMRG:
 
     def _finish_site(self, isw, i, e, ndav, psi, kinfo):
         self.psi = (psi, kinfo)
+        self.site_key = (isw, i)
         self.energies[(isw, i)], self.ndav[(isw, i)] = e, ndav
 
     def _move_to(self, i, forward):

@@ -87,6 +87,11 @@ typedef struct b2x_plan_stats {
     uint64_t n_staged;        /* operands copied into plan-owned memory because a 16-byte fetch would otherwise touch the
                                  element behind the caller's buffer (operands that end exactly at the end of psi or of an
                                  adopted arena): arena operands once at plan creation, psi operands per execute */
+    /* the three rewrites of the pair list (all zero with keep_order = 1) */
+    uint64_t n_flipped;         /* pairs taken in the other association, (op(Z).X).op(Y) */
+    uint64_t n_shared_products; /* pairs that reuse the stage-0 product of another pair */
+    uint64_t n_merged_groups;   /* groups of pairs whose scaled stage-0 products are summed before ONE stage-1 product */
+    uint64_t n_merged_members;  /* pairs in those groups */
 } b2x_plan_stats;
 
 /* tuning knobs; pass NULL for defaults */
@@ -228,13 +233,18 @@ int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term
  * device-resident vectors of this path: ParallelTensorFunctions::operator() sums the partial H.psi of the ranks
  * (src/core/parallel_tensor_functions.hpp:51-55), the diagonal is summed once per site (:853), Davidson broadcasts from
  * the root.  Transport: RCCL (over xGMI inside a node); one process per GPU; the communicator binds to the device that
- * is current when it is created (call b2x_device_init first).  Rendezvous without MPI: rank 0 writes the 128-byte RCCL
- * id to `id_file` (a path every rank can read — any local directory on one node; the caller removes it afterwards), the
- * other ranks wait for it (120 s).  A launcher with its own broadcast uses b2x_comm_unique_id + b2x_comm_init_id.
+ * is current when it is created (call b2x_device_init first).  Rendezvous without MPI (b2x_comm_init_session): rank 0
+ * removes whatever is at `id_file` (a path every rank can read — any local directory on one node), writes {magic, nonce,
+ * 128-byte RCCL id} there and removes the file again once the communicator exists; the other ranks wait for a file that
+ * carries THEIR `nonce` (B2X_COMM_TIMEOUT_S, default 120 s) — the file a crashed earlier run left behind is rejected, not
+ * joined.  `nonce` = any number all ranks of one launch share and earlier launches did not (the launcher's run id, a
+ * time stamp broadcast by its control plane); 0 accepts any file: b2x_comm_init(id_file) is that form, safe only where
+ * no earlier file can exist at the path.  A launcher with its own broadcast uses b2x_comm_unique_id + b2x_comm_init_id.
  * Collectives are asynchronous and ordered on `stream` (hipStream_t, NULL = default stream): they run on the
  * communicator's own stream once the work queued on `stream` so far is done, and `stream` resumes after them. */
 typedef struct b2x_comm b2x_comm;
 int b2x_comm_init(b2x_comm **out, int rank, int size, const char *id_file);
+int b2x_comm_init_session(b2x_comm **out, int rank, int size, const char *id_file, uint64_t nonce);
 int b2x_comm_unique_id(void *id128);                                   /* rank 0: a fresh 128-byte id */
 int b2x_comm_init_id(b2x_comm **out, int rank, int size, const void *id128);
 int b2x_comm_rank(const b2x_comm *c, int *rank, int *size);

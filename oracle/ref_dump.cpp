@@ -33,12 +33,22 @@
  *                                            its content as named arrays (on-disk format fixture)
  *   fp_prec=<x> [fp_chunk=<n>]               (with tensor_file=) also write the tensor in compressed storage, <file>.fpc
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
+ *   stack_gb=<n>  main_stack=1  keep_part=1   size of the double stack; operators on the frame stack (block2's default);
+ *                                            partition files left in the scratch directory
+ *   dav_thrd=<x>                             Davidson threshold of EVERY sweep (the default loosens it to noise / 10 in noisy sweeps)
  *   prefactors=1                             (with para=) also write ParallelRuleSimple::index_prefactor of every (i,j), (i,j,k,l)
  *   para=i|ij                                sum-MPO parallel rule (ParallelRuleSimple I / IJ); under mpirun with the
  *                                            _HAS_MPI build every rank writes <outprefix>.r<rank>of<size>.*
  *   chain=<last sweep>  nodelay=1  nocache=1  every blocking / rotation / effective Hamiltonian from the initial environments
  *                                            up to that sweep at the symbolic level, numbered in call order, without bulk data
  *                                            (fixtures of the site-to-site chain; needs nodelay=1)
+ *                                            with noise != 0 the perturbative-noise step of every site is an event of its own
+ *                                            (<kind> = enoise: the eham content + sub-labels + perturbed-ket infos, no bulk data)
+ *   spectra=1                                log, per site, the FULL density-matrix spectrum the reference truncated
+ *                                            (DMRG::store_wfn_spectra: sqrt of every eigenvalue, sector by sector, before the cut)
+ *                                            and the discarded weight: "SPECTRA <sweep> <site> <error> <n> <values...>"
+ *   (always)                                 "SWEEP_TIME <sweep> <wall s> teff teig tprt tblk tmve tdm tsplt tsvd ndav nflop":
+ *                                            the reference's own per-sweep timers (sweep_algorithm.hpp:3208-3217)
  *   stop_after=<sweep>:<site>                leave the run right after the captures of that site (large-M structure runs)
  */
 #include "block2_core.hpp"
@@ -900,6 +910,8 @@ template <typename S> struct Dumper : CallbackKernel {
                                // (isw even) == start_forward (src/dmrg/sweep_algorithm.hpp:3076-3101)
     mutable vector<string> log;
     pair<int, int> stop_after = make_pair(-1, -1);
+    bool spectra = false;
+    mutable Timer sweep_timer;
     mutable map<pair<int, int>, string> pending; // file awaiting psi_out / energy
     void compute(const string &name, int iprint) const override {
         if (dmrg == nullptr)
@@ -933,10 +945,32 @@ template <typename S> struct Dumper : CallbackKernel {
             bool wd = spec.pnoise.count(key), st = spec.pnoise_struct.count(key), en = spec.enoise.count(key);
             if (wd || st || en)
                 capture_pnoise(isw, site, wd, st, en);
+            // chain mode, noisy sweep: the perturbative-noise step of this site as an event of its own (symbolic level only)
+            if (spec.lite() && isw <= spec.chain && (dmrg->noise_type & NoiseTypes::Perturbative) &&
+                isw < (int)dmrg->noises.size() && dmrg->noises[isw] != 0)
+                capture_pnoise(isw, site, false, false, true, spec.next_event("enoise", isw, site) + ".enoise", true);
         } else if (name == "DMRG::sweep::iter.end") {
             stringstream ss;
             ss.precision(15);
             ss << "SITE_ENERGY " << isw << " " << site << " " << dmrg->sweep_energies.back()[0];
+            log.push_back(ss.str());
+            if (spectra) { // the spectrum split_density_matrix truncated at this site (all eigenvalues, sector by sector)
+                stringstream sp;
+                sp.precision(17);
+                sp << "SPECTRA " << isw << " " << site << " " << dmrg->sweep_discarded_weights.back() << " "
+                   << dmrg->wfn_spectra.size();
+                for (auto x : dmrg->wfn_spectra)
+                    sp << " " << x;
+                log.push_back(sp.str());
+            }
+        } else if (name == "DMRG::sweep.start") {
+            sweep_timer.get_time();
+        } else if (name == "DMRG::sweep.end") {
+            stringstream ss;
+            ss.precision(9);
+            ss << "SWEEP_TIME " << isw << " " << sweep_timer.get_time() << " " << dmrg->teff << " " << dmrg->teig << " "
+               << dmrg->tprt << " " << dmrg->tblk << " " << dmrg->tmve << " " << dmrg->tdm << " " << dmrg->tsplt << " "
+               << dmrg->tsvd << " " << dmrg->me->trot << " " << dmrg->me->tctr << " " << (double)dmrg->sweep_cumulative_nflop;
             log.push_back(ss.str());
         }
     }
@@ -1061,7 +1095,8 @@ template <typename S> struct Dumper : CallbackKernel {
     }
     // perturbative noise: run the reference's own EffectiveHamiltonian::perturbative_noise with the capturing
     // TensorFunctions swapped in, exactly as DMRG::update_two_dot calls it (src/dmrg/sweep_algorithm.hpp:799-802)
-    void capture_pnoise(int isw, int site, bool with_data, bool structure, bool symbolic) const {
+    void capture_pnoise(int isw, int site, bool with_data, bool structure, bool symbolic, const string &sym_file = "",
+                        bool lite = false) const {
         auto h = dmrg->current_eff_ham;
         auto cap = make_shared<CapTF<S>>(h->tf->opf);
         auto old_tf = h->tf;
@@ -1111,10 +1146,17 @@ template <typename S> struct Dumper : CallbackKernel {
         }
         if (symbolic) {
             stringstream efn;
-            efn << spec.prefix << ".sw" << isw << ".site" << site << ".enoise";
+            if (sym_file.empty())
+                efn << spec.prefix << ".sw" << isw << ".site" << site << ".enoise";
+            else
+                efn << sym_file;
             EhamDump<S> ed(efn.str());
             ArrayFile &af = ed.af;
+            af.lite = lite;
             EhamOrders eo = write_eham_common(ed, h);
+            if (lite)
+                af.u64("chain.meta", vector<uint64_t>{(uint64_t)isw, (uint64_t)site, (uint64_t)dmrg->me->n_sites,
+                                                      (uint64_t)forward});
             auto lopt = h->op->lopt, ropt = h->op->ropt;
             shared_ptr<OpExpr<S>> i_op = make_shared<OpElement<S, FL>>(OpNames::I, SiteIndex(), S());
             vector<int64_t> iop{EhamDump<S>::find_op(lopt, eo.l, i_op), EhamDump<S>::find_op(ropt, eo.r, i_op), -1, -1};
@@ -1137,9 +1179,11 @@ template <typename S> struct Dumper : CallbackKernel {
             af.i64("noise.args", vector<int64_t>{(int64_t)cap->a_trace_right, (int64_t)cap->a_vidx, (int64_t)cap->a_tvidx,
                                                  (int64_t)n, (int64_t)macs, (int64_t)cap->out_len});
             af.u64("noise.vacuum", vector<uint64_t>{dmrg->me->ket->info->vacuum.data});
-            af.f64("psi", h->ket->data, h->ket->total_memory);
-            af.f64("out_ref", pket->data, pket->total_memory);
-            cerr << "ENOISE " << efn.str() << " gemms=" << n << endl;
+            af.f64("noise.value", vector<double>{isw < (int)dmrg->noises.size() ? (double)dmrg->noises[isw] : 0.0});
+            af.bulk("psi", h->ket->data, h->ket->total_memory);
+            af.bulk("out_ref", pket->data, pket->total_memory);
+            if (!lite)
+                cerr << "ENOISE " << efn.str() << " gemms=" << n << endl;
         }
         if (with_data || structure) {
         stringstream fn;
@@ -1288,9 +1332,12 @@ template <typename S>
 int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string, string> &kv) {
     typedef double FL;
     size_t isize = 1LL << 28, dsize = 1LL << 33;
+    if (kv.count("stack_gb")) // (bytes of the double stack; large-M structure runs need more than the 8 GB default)
+        dsize = (size_t)Parsing::to_int(kv["stack_gb"]) << 30;
     int nth = kv.count("nthreads") ? Parsing::to_int(kv["nthreads"]) : 8;
     frame_<double>() = make_shared<DataFrame<double>>(isize, dsize, kv.count("scratch") ? kv["scratch"] : "/tmp/b2x_ref_scratch");
-    frame_<double>()->use_main_stack = false;
+    frame_<double>()->use_main_stack = kv.count("main_stack") != 0; // (main_stack=1: block2's default — renormalised operators
+                                                                    //  live on the frame's stack and go into the partition files)
     frame_<double>()->minimal_disk_usage = true;
     threading_() = make_shared<Threading>(ThreadingTypes::OperatorBatchedGEMM | ThreadingTypes::Global, nth, nth, 1);
     threading_()->seq_type = SeqTypes::Tasked;
@@ -1426,11 +1473,15 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     dmrg->noise_type = NoiseTypes::ReducedPerturbative;
     dmrg->decomp_type = DecompositionTypes::DensityMatrix;
     dmrg->davidson_soft_max_iter = kv.count("dav_iter") ? Parsing::to_int(kv["dav_iter"]) : 4000;
+    if (kv.count("dav_thrd")) // (default: noise * 0.1 in a noisy sweep, tol * 0.1 otherwise, sweep_algorithm.hpp:3038-3047)
+        dmrg->davidson_conv_thrds = vector<double>(max(n_sweeps, 1), Parsing::to_double(kv["dav_thrd"]));
     dumper->dmrg = dmrg.get();
     dumper->start_forward = mps->center == 0;
     rtf_set_dmrg(dmrg.get());
     if (kv.count("stop_after"))
         dumper->stop_after = *parse_pairs(kv["stop_after"]).begin();
+    if (kv.count("spectra"))
+        dumper->spectra = true, dmrg->store_wfn_spectra = true;
     if (kv.count("dump"))
         dumper->spec.with_data = parse_pairs(kv["dump"]);
     if (kv.count("struct"))
@@ -1504,7 +1555,8 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     // teardown in the order the reference's own tests use (unit_test/test_dmrg_n2_sto3g.cpp:121-122, 142, 236-237, 39-43):
     // persistent stack memory is released explicitly, newest first, before the frame goes away
     mps_info->deallocate();
-    me->remove_partition_files();
+    if (!kv.count("keep_part")) // keep_part=1: the partition files stay in scratch= (on-disk format fixtures)
+        me->remove_partition_files();
     mpo->deallocate();
     hamil->deallocate();
     fcidump->deallocate();

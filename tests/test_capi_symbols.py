@@ -48,3 +48,22 @@ def test_product_library_carries_no_host_emulator(built):
     for name in ("b2x_debug_compile_and_emulate", "b2x_debug_compile_and_emulate_gemms",
                  "b2x_debug_compile_and_emulate_outer", "b2x_debug_compile_diag"):
         assert not hasattr(lib, name), name
+
+
+def test_comm_rendezvous_rejects_a_stale_id_file(built, tmp_path, monkeypatch):
+    """b2x_comm_init_session: a rank other than 0 accepts only a complete id file that carries the session's nonce.  The
+    file a crashed earlier run left at the same path (another nonce, or no header at all) is rejected with an error that
+    says so — it is never handed to ncclCommInitRank.  (No device needed: the wait ends before RCCL is touched.)"""
+    import struct
+
+    monkeypatch.setenv("B2X_COMM_TIMEOUT_S", "1")
+    stale = tmp_path / "rccl_id"
+    stale.write_bytes(b"B2XID001" + struct.pack("<Q", 1111) + bytes(128))  # an earlier session's id
+    with pytest.raises(capi.B2XError, match="stale id rejected"):
+        capi.Comm(1, 2, id_file=str(stale), nonce=2222)
+    assert stale.exists()  # only rank 0 ever removes or replaces the file
+    stale.write_bytes(bytes(128))  # the headerless format of round 2: rejected even when no nonce is asked for
+    with pytest.raises(capi.B2XError, match="stale id rejected"):
+        capi.Comm(1, 2, id_file=str(stale))
+    with pytest.raises(capi.B2XError, match="no id of this session"):
+        capi.Comm(1, 2, id_file=str(tmp_path / "never_written"), nonce=5)

@@ -340,3 +340,24 @@ def test_edge_widths_and_depths(gpu, wide):
         sig, st = _run(gpu, pf, 0.5, **kw)
         assert st["fallback"] == 0 and st["macs_issued"] >= st["macs_executed"] > 0
         assert _close(sig, ref), kw
+
+
+@pytest.mark.parametrize("seed", [1, 4, 6])
+def test_distributive_law_sum_pass_vs_oracle(gpu, seed):
+    """the sum pass between the stages (pairs of one psi' sector that multiply the SAME operator block into the SAME window
+    first sum their scaled stage-0 products, S = sum alpha_i W_i, then take ONE stage-1 product; b2x_plan.cpp "6b merge
+    groups") pinned DIRECTLY against the pair-by-pair oracle: plans with many terms per left operator and blocks wide enough
+    for the rewrite to qualify, b2x_plan_stats.n_merged_groups > 0 asserted, 1e-12; keep_order = 1 (none of the rewrites)
+    gives the same sigma"""
+    rng = np.random.default_rng(900 + seed)
+    pf = fill_plan(synth.operator_product_plan(rng, n_row=2, n_col=3, max_dim=420, n_left=2, n_right=6, n_terms=14), seed)
+    ref = np.zeros(pf.sigma_len)
+    oracle.replay(pf.pairs, pf.arena, pf.psi, ref, 1.0, 8)
+    sig, st = _run(gpu, pf)
+    assert st["n_merged_groups"] >= 20 and st["n_merged_members"] > 2 * st["n_merged_groups"], st
+    assert st["n_shared_products"] > 0 and st["n_flipped"] > 0 and st["fallback"] == 0
+    assert _close(sig, ref), st
+    plain, st1 = _run(gpu, pf, keep_order=1)
+    assert st1["n_merged_groups"] == st1["n_shared_products"] == st1["n_flipped"] == 0
+    assert _close(plain, ref)
+    assert st["macs_executed"] < 0.5 * st1["macs_executed"]  # the rewrites, not rounding luck, are what was tested

@@ -167,3 +167,26 @@ def test_compilations_are_independent_of_what_was_compiled_before(built):
         run(pf, **kw)
         again, st1 = run(small)
         assert np.array_equal(first, again) and st0 == st1
+
+
+def test_sum_pass_groups_are_counted_and_exact(built):
+    """b2x_plan_stats counts the three rewrites of the pair list; the compiled work list of a plan WITH merged groups
+    (distributive-law sum pass) evaluated by host loops equals the pair-by-pair oracle"""
+    import hooks
+    from block2_preview_amd import synth
+    from oracle import oracle
+
+    rng = np.random.default_rng(904)
+    pf = synth.operator_product_plan(rng, n_row=2, n_col=3, max_dim=420, n_left=2, n_right=6, n_terms=14)
+    g = np.random.default_rng(4)
+    pf.arena, pf.psi = g.random(pf.arena_len), g.random(pf.psi_len)
+    sig, ref = np.zeros(pf.sigma_len), np.zeros(pf.sigma_len)
+    st, fb = hooks.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, pf.arena, pf.psi, sig)
+    oracle.replay(pf.pairs, pf.arena, pf.psi, ref, 1.0, 4)
+    assert not fb and st["n_merged_groups"] >= 20 and st["n_merged_members"] > 2 * st["n_merged_groups"]
+    assert st["n_shared_products"] > 0 and st["n_flipped"] > 0
+    assert np.abs(sig - ref).max() <= 1e-12 * np.abs(ref).max()
+    sig1 = np.zeros(pf.sigma_len)
+    st1, _ = hooks.debug_compile_and_emulate(pf.pairs, pf.psi_len, pf.sigma_len, pf.arena, pf.psi, sig1, keep_order=1)
+    assert st1["n_merged_groups"] == st1["n_shared_products"] == st1["n_flipped"] == 0
+    assert np.abs(sig1 - ref).max() <= 1e-12 * np.abs(ref).max()

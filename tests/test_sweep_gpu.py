@@ -167,3 +167,50 @@ def test_cr2_svp_chain_m30(gpu):
     assert all(d[(0, i)] < 1e-9 for i in range(6))
     assert max(d.values()) < 5e-5
     assert min(es) <= fx.final_energy + 1e-7 and abs(min(es) - fx.final_energy) < 1e-5
+
+
+def _noisy(gpu, prefix, sym, n_sweeps, n_noisy_sites):
+    from block2_preview_amd.sweep import DMRG, ChainFixture
+
+    fx = ChainFixture(os.path.join(GOLDEN, prefix))
+    assert sum(1 for _, k, _ in fx.events if k == "enoise") == n_noisy_sites
+    dm = DMRG(fx, sym)
+    dm.check_truncation = True
+    dm.init_environments()
+    es = []
+    for isw in range(n_sweeps):
+        es += dm.sweep(isw, isw % 2 == 0)
+    assert fx.pos == len(fx.events)
+    return fx, dm, es
+
+
+def test_n2_noisy_schedule_chain(gpu):
+    """block2's schedules start with noisy sweeps (dmrg_driver.hpp:415-464): N2/STO-3G SU2 M=200 with noises 1e-5, 1e-5, 0
+    (NoiseTypes::ReducedPerturbative, as the reference's default).  In the noisy sweeps every site runs, after its Davidson,
+    perturbative noise on the device (symbolic walk -> b2x_gemm_plan over the H.psi arena), the density matrix of psi PLUS
+    the scaled perturbed wavefunctions, and the split of THAT matrix (sweep_algorithm.hpp:1252-1255, effective_hamiltonian.hpp:
+    252-423, moving_environment.hpp:3512-3538).  All 27 site energies of the reference's run and the known answer."""
+    fx, dm, es = _noisy(gpu, os.path.join("chain_n2su2_noisy", "n2n"), "su2", 3, 18)
+    worst = max(abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items())
+    print("N2 noisy: worst |dE| = %.2e, final %.12f, noise timers %s" % (
+        worst, es[-1], {k: round(v, 3) for k, v in dm.tm.items() if k.startswith("noise")}))
+    assert len(fx.ref_energy) == 27 and worst < 1e-7
+    assert abs(es[-1] - (-107.654122447525)) < 1e-7
+    # the density matrix that was split is the reference's: its whole spectrum (SPECTRA lines of the fixture's log, every
+    # eigenvalue of every sector before the cut) agrees to 2e-7 — eigenvalues move in first order with the 1e-7 the two
+    # Davidson solutions differ by — where the noise itself carries a weight of 1e-5
+    noisy = [v for k, v in dm.trunc_log.items() if k[0] < 2 and "spectrum_max_abs_diff" in v]
+    assert len(noisy) == 16 and max(v["spectrum_max_abs_diff"] for v in noisy) < 2e-7
+
+
+def test_h10_noisy_schedule_chain(gpu):
+    """the same on BASELINE configs[1]'s molecule at M=500, SZ: noises 1e-5, 1e-5, 0 — 18 noisy sites, 27 site energies and
+    the in-tree answer -5.424385376237"""
+    fx, dm, es = _noisy(gpu, os.path.join("chain_h10sz_noisy", "h10n"), "sz", 3, 18)
+    first = (0, 0)  # (the reference's first Davidson starts from its random MPS and may stop in an excited state: see above)
+    worst = max(abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items() if k != first)
+    print("H10 noisy: worst |dE| = %.2e, final %.12f" % (worst, min(es)))
+    assert len(fx.ref_energy) == 27 and worst < 1e-7
+    assert abs(min(es) - (-5.424385376237)) < 1e-7
+    noisy = [v for k, v in dm.trunc_log.items() if k[0] < 2 and k != first and "spectrum_max_abs_diff" in v]
+    assert len(noisy) == 15 and max(v["spectrum_max_abs_diff"] for v in noisy) < 2e-7
