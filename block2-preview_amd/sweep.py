@@ -78,6 +78,13 @@ class ChainFixture:
     def peek(self):
         return self.events[self.pos][1] if self.pos < len(self.events) else None
 
+    def find_next(self, kind):
+        """(event number, arrays) of the next event of this kind at or after the cursor, without moving the cursor"""
+        for n, k, fn in self.events[self.pos:]:
+            if k == kind:
+                return n, read_arrays(fn)
+        return None, None
+
 
 class OpTensor:
     """operator blocks of one (enlarged or rotated) block in HBM: one device vector + {operator key: (offset, length)}"""
@@ -131,6 +138,8 @@ class DMRG:
         self.check_truncation = False    # True: every split also makes its OWN choice of kept states and logs where it
         self.trunc_log = {}              # differs from the fixture's bond dimensions (see _split)
         self.site_key = None
+        self.ahead = None                # (event number, new MPS tensor): a split made before the move (split_site)
+        self.last_split = None           # {"error": discarded weight, "mmps": kept states} of the last split
 
     # ---- steps ------------------------------------------------------------------------------------------------
     def _assign(self, d):
@@ -417,6 +426,28 @@ class DMRG:
                 out.append((mats[j], pk["infos"][j], self._bond_labels(pk["infos"][j], right)))
         return out
 
+    def split_site(self, forward):
+        """the decomposition of the wavefunction just solved, made BEFORE the move to the next site — where block2 makes it
+        (DMRG::update_two_dot, sweep_algorithm.hpp:940-960) — from the rotation event the move will consume; at the
+        turn-around site of a sweep there is none (the next sweep solves the same two sites again).  Returns
+        {"error": discarded weight, "mmps": kept states} or None."""
+        n, i = self.n_sites, self.site_key[1]
+        if (forward and i == n - 2) or (not forward and i == 0):
+            return None
+        num, d = self.fx.find_next("lrot" if forward else "rrot")
+        if d is None:
+            return None
+        self.ahead = (num, self._split(d, not forward))
+        return self.last_split
+
+    def _take_split(self, d, right):
+        num = self.fx.events[self.fx.pos - 1][0]
+        if self.ahead is not None and self.ahead[0] == num:
+            a, self.ahead = self.ahead[1], None
+            return a
+        self.ahead = None
+        return self._split(d, right)
+
     def _split(self, d, right):
         """new MPS tensor = the dominant eigenvectors of the density matrix of psi (DensityMatrix decomposition,
         src/dmrg/moving_environment.hpp density_matrix :3512-3538 / split_density_matrix :4218-), per quantum-number sector
@@ -444,16 +475,20 @@ class DMRG:
             return rho
 
         kept_of, spectrum = {}, {}
+        kept_w, mmps = 0.0, 0
         for s in range(len(ainfo["q"])):
             key = (int(an[s]), int(atw[s]), int(apg[s]))
             rows, cols = int(ainfo["nbra"][s]), int(ainfo["nket"][s])
             fused, kept = (cols, rows) if right else (rows, cols)
             w, u = np.linalg.eigh(rho_of(key, fused))
             kept_of[key], spectrum[key] = kept, w[::-1]
+            kept_w, mmps = kept_w + float(w[::-1][:kept].sum()), mmps + kept
             u = u[:, ::-1][:, :kept]  # largest weights first
             blk = u.T if right else u
             o = base + int(ainfo["ntot"][s])
             out[o:o + rows * cols] = blk.reshape(-1)
+        trace = sum(float(data @ data) for data, _, _ in srcs)
+        self.last_split = {"error": max(0.0, trace - kept_w), "mmps": mmps}
         if self.check_truncation:
             self._check_truncation(right, kept_of, spectrum, rho_of)
         self.tm.add("split", t0)
@@ -558,7 +593,7 @@ class DMRG:
             if i > 0:  # move_to(i): rotate the enlarged left block of the previous site with the new MPS tensor
                 _, d = fx.next("lasg", "lblk")   # (the reference re-contracts it; it is still in HBM here)
                 _, d = fx.next("lrot")
-                a = self._split(d, False)
+                a = self._take_split(d, False)
                 self.L[i] = self._rotate_and_transform(d, self.EL, a)
             if self.EL is not None:
                 self.EL.close()
@@ -576,7 +611,7 @@ class DMRG:
             if i < n - 2:  # move_to(i): rotate the enlarged right block of the previous site
                 _, d = fx.next("rasg", "rblk")
                 _, d = fx.next("rrot")
-                a = self._split(d, True)
+                a = self._take_split(d, True)
                 if i + 2 in self.R:
                     self.R[i + 2].close()
                 self.R[i + 2] = self._rotate_and_transform(d, self.ER, a)

@@ -136,3 +136,94 @@ def test_effective_kernel_hook(gpu):
     e2, _, _, _, _ = eh.eigs(pf.psi.tolist(), conv_thrd=1e-12, max_iter=500)
     eh.post_precompute()
     assert abs(e2 - (e0 + 3.0)) < 1e-9
+
+
+def test_sweep_layer_names_exist(built):
+    """block2's sweep-layer names (src/pybind/pybind_dmrg.hpp:773-900 MovingEnvironment, :1298-1380 DMRG, :1679-1775
+    ParallelRuleSimple / ParallelFCIDUMP / ParallelMPO; DMRGDriver: src/dmrg/dmrg_driver.hpp:415-464) under the module"""
+    from block2_preview_amd import dmrg
+
+    b = dmrg.b2x_host
+    for sub in (b.su2, b.sz):
+        for name in ("MovingEnvironment", "DMRG", "ParallelRuleSimple", "ParallelFCIDUMP", "ParallelMPO", "MPS", "MPO",
+                     "TensorFunctions", "ParallelTensorFunctions", "OperatorFunctions"):
+            assert hasattr(sub, name), name
+    for name in ("DMRGDriver", "NoiseTypes", "TruncationTypes", "DecompositionTypes", "FuseTypes", "EffectiveHamiltonian"):
+        assert hasattr(b, name), name
+    for m in ("init_environments", "move_to", "eff_ham", "left_contract_rotate", "right_contract_rotate"):
+        assert callable(getattr(b.su2.MovingEnvironment, m))
+    for m in ("solve", "sweep", "blocking", "update_two_dot"):
+        assert callable(getattr(b.su2.DMRG, m))
+    # the reference's defaults (sweep_algorithm.hpp:60-130)
+    dx = b.su2.DMRG.__new__(b.su2.DMRG)
+    b.su2.DMRG.__init__(dx, None, [200], [0.0])
+    assert dx.davidson_def_max_size == 50 and dx.cutoff == 1e-14 and dx.decomp_type == b.DecompositionTypes.DensityMatrix
+    assert b.NoiseTypes.ReducedPerturbative == b.NoiseTypes.Perturbative | b.NoiseTypes.Reduced
+
+
+@pytest.mark.gpu
+def test_n2_energy_gate_through_block2_names(gpu):
+    """the N2/STO-3G energy gate driven the way a block2 user writes it (unit_test/test_dmrg_n2_sto3g.cpp:88-148):
+    MovingEnvironment(mpo, mps, mps, "DMRG"), init_environments(), DMRG(me, bond_dims, noises), solve(n_sweeps, forward, tol)
+    — and once more through DMRGDriver.dmrg — every site energy of the reference run and -107.654122447525"""
+    from block2_preview_amd import dmrg
+
+    b = dmrg.b2x_host
+    prefix = os.path.join(GOLDEN, "chain_n2su2", "n2c")
+    mpo, mps = b.su2.MPO(prefix, "su2"), b.su2.MPS(center=0, dot=2)
+    me = b.su2.MovingEnvironment(mpo, mps, mps, "DMRG")
+    me.init_environments(False)
+    assert me.n_sites == 10 and mps.n_sites == 10
+    dx = b.su2.DMRG(me, [200], [0.0, 0.0])
+    dx.noise_type, dx.iprint = b.NoiseTypes.ReducedPerturbative, 0
+    dx.davidson_conv_thrds = [1e-13, 1e-13]
+    e = dx.solve(2, mps.center == 0, 1e-12)
+    ref = mpo.fixture.ref_energy
+    got = {k: v for k, v in me._eng.energies.items()}
+    assert len(got) == 18 and max(abs(got[k] - ref[k]) for k in ref) < 1e-7
+    assert abs(e - (-107.654122447525)) < 1e-7 and len(dx.energies) == 2 and len(dx.sweep_time) == 2
+    assert dx.forward is True and dx.discarded_weights[1] < 1e-9 and dx.sweep_cumulative_nflop > 0
+    assert set(mps.tensors) >= set(range(1, 9))  # every split left its MPS tensor behind
+    # a schedule the chain was not recorded with is refused, not silently replaced
+    mpo2, mps2 = b.su2.MPO(prefix, "su2"), b.su2.MPS()
+    me2 = b.su2.MovingEnvironment(mpo2, mps2, mps2)
+    me2.init_environments()
+    dn = b.su2.DMRG(me2, [200], [1e-5])
+    dn.noise_type = b.NoiseTypes.ReducedPerturbative
+    with pytest.raises(RuntimeError, match="recorded without noise"):
+        dn.solve(1, True, 1e-8)
+    # the driver entry: same arguments and defaults as DMRGDriver::dmrg
+    drv = b.DMRGDriver(symm_type="su2")
+    mpo3 = drv.get_chain_mpo(prefix)
+    e3 = drv.dmrg(mpo3, drv.get_chain_mps(mpo3, bond_dim=200), n_sweeps=2, tol=1e-12, bond_dims=[200], noises=[0.0],
+                  thrds=[1e-13])
+    assert abs(e3 - (-107.654122447525)) < 1e-7
+
+
+@pytest.mark.gpu
+def test_noisy_schedule_and_sum_mpo_through_block2_names(gpu):
+    """DMRG.solve with the reference's noisy schedule (noises 1e-5, 1e-5, 0: perturbative noise inside update_two_dot) and a
+    ParallelMPO over the two ranks' chains of the reference's mpirun -n 2 run (ParallelRuleSimple IJ)"""
+    from block2_preview_amd import dmrg
+
+    b = dmrg.b2x_host
+    mpo, mps = b.su2.MPO(os.path.join(GOLDEN, "chain_n2su2_noisy", "n2n"), "su2"), b.su2.MPS()
+    me = b.su2.MovingEnvironment(mpo, mps, mps, "DMRG")
+    me.init_environments()
+    dx = b.su2.DMRG(me, [200], [1e-5, 1e-5, 0.0])
+    dx.noise_type, dx.iprint, dx.davidson_conv_thrds = b.NoiseTypes.ReducedPerturbative, 0, [1e-13] * 3
+    e = dx.solve(3, True, 1e-12)
+    ref = mpo.fixture.ref_energy
+    assert max(abs(me._eng.energies[k] - ref[k]) for k in ref) < 1e-7 and abs(e - (-107.654122447525)) < 1e-7
+    from block2_preview_amd import parallel
+
+    rule = b.su2.ParallelRuleSimple("IJ", parallel.ParallelCommunicator(2, 0, 0))
+    ranks = [b.su2.MPO(os.path.join(GOLDEN, "chain_n2su2_ij", "n2p.r%dof2" % r), "su2") for r in range(2)]
+    pmpo, pmps = b.su2.ParallelMPO(ranks, rule), b.su2.MPS()
+    pme = b.su2.MovingEnvironment(pmpo, pmps, pmps, "DMRG")
+    pme.init_environments()
+    px = b.su2.DMRG(pme, [200], [0.0, 0.0])
+    px.noise_type, px.iprint, px.davidson_conv_thrds = b.NoiseTypes.ReducedPerturbative, 0, [1e-13] * 2
+    ep = px.solve(2, True, 1e-12)
+    pref = ranks[0].fixture.ref_energy
+    assert max(abs(pme._eng.energies[k] - pref[k]) for k in pref) < 1e-7 and abs(ep - (-107.654122447525)) < 1e-7
