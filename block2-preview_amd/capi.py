@@ -98,9 +98,11 @@ class DeviceBuffer:
         p = C.c_void_p()
         check(lib().b2x_device_alloc(C.byref(p), C.c_size_t(max(1, n) * 8)))
         self.ptr, self.n = p.value, n
-        if host is None:
-            host = np.zeros(n)
-        self.upload(host)
+        if host is None:  # zero-filled on the device (no host array, no PCIe copy)
+            if n:
+                check(lib().b2x_vec_zero(C.c_void_p(self.ptr), C.c_size_t(n), None))
+        else:
+            self.upload(host)
 
     def upload(self, host):
         host = np.ascontiguousarray(host, np.float64)

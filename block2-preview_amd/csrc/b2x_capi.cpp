@@ -194,6 +194,7 @@ struct b2x_plan {
     double *g_sigma = nullptr;
     double g_scale = 0;
     bool graph_failed = false;
+    uint32_t n_device_exec = 0; // device-pointer executes of this binding so far (the graph is captured at the second)
     // what re-binding a cached plan to the next site's arena needs (plan_bind) and the cache key (see g_plan_cache)
     uint64_t scratch_elems = 0, gslab_elems = 0, slab_elems = 0;
     std::vector<StageCopy> stage_arena; // staged operands with an arena source: copied at every bind
@@ -225,7 +226,7 @@ static void plan_unbind(b2x_plan *p) {
     if (p->graph)
         (void)hipGraphDestroy(p->graph), p->graph = nullptr;
     p->gnodes.clear();
-    p->g_psi = nullptr, p->g_sigma = nullptr, p->graph_failed = false;
+    p->g_psi = nullptr, p->g_sigma = nullptr, p->graph_failed = false, p->n_device_exec = 0;
     p->arena = nullptr;
 }
 
@@ -738,6 +739,10 @@ static int run_plan_graph(b2x_plan *p, const double *psi, double *sigma, double 
     const char *genv = getenv("B2X_GRAPH"); // (read per call: the tests switch it inside one process)
     const int enabled = genv ? atoi(genv) : 1;
     if (!enabled || p->graph_failed || p->fallback || !p->stage_in.empty())
+        return kGraphUnavailable;
+    // The first device-pointer execute of a plan launches directly; the graph is captured at the second: a plan that runs
+    // once (the rotation of a block, 16 ms of capture + instantiation against 1 ms of work at M=250) never pays for it.
+    if (!p->gexec && p->n_device_exec++ == 0)
         return kGraphUnavailable;
     auto give_up = [&]() {
         p->graph_failed = true;

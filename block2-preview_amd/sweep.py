@@ -98,11 +98,15 @@ class OpTensor:
 
 
 def _info(d, i):
-    pre = "info.%d." % int(i)
-    q = d[pre + "quanta"].astype(np.uint64)
-    return {"q": q, "nbra": d[pre + "nbra"].astype(np.int64), "nket": d[pre + "nket"].astype(np.int64),
-            "ntot": d[pre + "ntot"].astype(np.int64), "dq": int(d[pre + "meta"][0]),
-            "len": int(d[pre + "meta"][3])}
+    memo = d.setdefault("_info_memo", {})  # (an event names the same info many times: once per operator)
+    v = memo.get(int(i))
+    if v is None:
+        pre = "info.%d." % int(i)
+        q = d[pre + "quanta"].astype(np.uint64)
+        v = memo[int(i)] = {"q": q, "nbra": d[pre + "nbra"].astype(np.int64), "nket": d[pre + "nket"].astype(np.int64),
+                            "ntot": d[pre + "ntot"].astype(np.int64), "dq": int(d[pre + "meta"][0]),
+                            "len": int(d[pre + "meta"][3])}
+    return v
 
 
 def _fields(q):
