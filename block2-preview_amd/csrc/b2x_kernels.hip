@@ -289,13 +289,6 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
     // overlap).  What depends on the lane alone is therefore computed once per ITEM (lane_consts; kept in registers for
     // tiles up to 64 rows, recomputed for the taller ones whose accumulators leave no room), the k clamp is a scalar
     // (min with 0xFFFF for a full chunk: no select), products are 24-bit multiply-adds, and the B mask is a bit count.
-    // A 16-byte A granule may reach ONE element behind its operand: a k-contiguous operand whose K is not a multiple of
-    // the chunk depth is read up to element K of every row, a row-contiguous one whose row count is not a multiple of 16
-    // up to row mr of every k.  Inside a buffer that element is the caller's own neighbouring (finite) data and meets a
-    // zeroed B lane; where it would lie OUTSIDE the buffer — the operand ends exactly at the end of an adopted arena or
-    // of psi — the plan compiler hands the kernel a staged copy instead (stage_residual_reads, b2x_plan.cpp), so no
-    // buffer needs slack.  (An exact variant of these offsets — last granule fetched one element earlier, B slots and
-    // the tile store following it — was measured: +13 % time at M=250, +6 % at M=500; profiles/README.md.)
     constexpr bool HOIST = NI <= 2; // (4 NI registers)
     auto lane_consts = [&](int j, uint32_t &row_c, uint32_t &k_ofs, uint32_t &rk, uint32_t &kl) __attribute__((always_inline)) {
         // granule G of the LDS image is written by lane `lane` of DMA instruction (wave, j)
@@ -361,6 +354,9 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
     // the A half of a fetch: this wave's share of the LDS-DMA of the chunk at k offset kb into LDS buffer `As`
     auto fetch_dma = [&](int kb, double *As) __attribute__((always_inline)) {
         const char *ba = (const char *)(sA + (uint64_t)((uint32_t)kb * astep));
+#ifdef B2X_PROBE_L2_WINDOW // (timing probe, wrong results: every operand fetch lands in the first MiB of the arena: all L2 hits)
+        ba = (const char *)arena + ((uint64_t)(uintptr_t)ba & 0xFFFF8ull);
+#endif
 #ifdef B2X_PROBE_NO_LOADS // (timing probe, wrong results)
         if (kb != 0x7fffffff)
             return;
@@ -376,6 +372,9 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
     auto fetch = [&](int kb, double *As) __attribute__((always_inline)) {
         fetch_dma(kb, As);
         const char *bb = (const char *)(sB + (uint64_t)((uint32_t)kb * bstep));
+#ifdef B2X_PROBE_L2_WINDOW
+        bb = (const char *)arena + ((uint64_t)(uintptr_t)bb & 0xFFFF8ull);
+#endif
         const uint32_t b_s4 = tail ? 0u : bstep * 32u; // bytes per k-step (a partial chunk keeps its k offsets per lane)
 #pragma unroll
         for (int s = 0; s < KS; s++) {

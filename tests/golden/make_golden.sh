@@ -75,9 +75,27 @@ mkdir -p chain_n2su2_ij
 mkdir -p chain_n2su2_ij4
 /opt/conda/bin/mpirun -n 4 ../../oracle/_ref/ref_dump_mpi $D/N2.STO3G.FCIDUMP su2 200 2 ./chain_n2su2_ij4/n2p para=ij chain=1 nocache=1 nthreads=1 noise=0,0 tol=1e-12 iprint=0
 # Cr2/SVP at M=30, two sweeps: 539 events, 51 MB raw -> kept as chain_cr2/cr2c.zip (sweep.ChainFixture unpacks it)
+# (round 3: spectra=1 logs the full density-matrix spectrum the reference truncated at every bond, dav_thrd the Davidson
+#  threshold of every sweep; SWEEP_TIME lines = the reference's own per-sweep timers)
+zipchain() { (cd $1 && python3 -c "import zipfile,glob,os; p='$2'; z=zipfile.ZipFile(p+'.zip','w',zipfile.ZIP_DEFLATED,compresslevel=9); [z.write(f) for f in sorted(glob.glob(p+'.ev*')+[p+'.log'])]; z.close()"); }
 mkdir -p chain_cr2 /tmp/b2x_cr2c
-$R $D/CR2.SVP.FCIDUMP su2 30 2 /tmp/b2x_cr2c/cr2c chain=1 nodelay=1 nocache=1 noise=0,0 tol=1e-12 iprint=0 occ=$D/CR2.SVP.OCC
-(cd /tmp/b2x_cr2c && python3 -c "import zipfile,glob,os; z=zipfile.ZipFile('cr2c.zip','w',zipfile.ZIP_DEFLATED,compresslevel=9); [z.write(f) for f in sorted(glob.glob('cr2c.ev*')+['cr2c.log'])]; z.close()") && cp /tmp/b2x_cr2c/cr2c.zip chain_cr2/
+$R $D/CR2.SVP.FCIDUMP su2 30 2 /tmp/b2x_cr2c/cr2c chain=1 nodelay=1 nocache=1 noise=0,0 tol=1e-12 dav_thrd=1e-13 spectra=1 iprint=0 occ=$D/CR2.SVP.OCC
+zipchain /tmp/b2x_cr2c cr2c && cp /tmp/b2x_cr2c/cr2c.zip chain_cr2/
+# THE Cr2 gate: M=250, the reference's noisy schedule, three sweeps: 845 events -> chain_cr2_m250_noisy/cr2n250.zip
+# (693 s on 3 threads here).  The noise-free variant (noise=0,0; 541 events) is the input of profiles/r03_cr2_m250_noise_free_trunc_diag.txt.
+mkdir -p chain_cr2_m250_noisy /tmp/b2x_cr2n250
+$R $D/CR2.SVP.FCIDUMP su2 250 3 /tmp/b2x_cr2n250/cr2n250 chain=2 nodelay=1 nocache=1 noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-13 spectra=1 iprint=1 occ=$D/CR2.SVP.OCC nthreads=3
+zipchain /tmp/b2x_cr2n250 cr2n250 && cp /tmp/b2x_cr2n250/cr2n250.zip chain_cr2_m250_noisy/
+# noisy schedules on N2 and H10 (noises 1e-5, 1e-5, 0: perturbative noise -> perturbed density matrix -> split in the chain)
+mkdir -p chain_n2su2_noisy chain_h10sz_noisy
+$R $D/N2.STO3G.FCIDUMP su2 200 3 ./chain_n2su2_noisy/n2n chain=2 nodelay=1 nocache=1 noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-13 iprint=0 spectra=1 nthreads=2
+$R $D/H10.STO6G.R1.8.FCIDUMP sz 500 3 ./chain_h10sz_noisy/h10n chain=2 nodelay=1 nocache=1 noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-13 iprint=0 spectra=1 nthreads=2
+zipchain chain_n2su2_noisy n2n && rm -f chain_n2su2_noisy/n2n.ev* chain_n2su2_noisy/n2n.log
+zipchain chain_h10sz_noisy h10n && rm -f chain_h10sz_noisy/h10n.ev* chain_h10sz_noisy/h10n.log
+# TRUE Cr2/SVP structures above M=250 (fixed-M run from a random MPS, two Davidson iterations per site, captured at sweep 1
+# site 20 like the M=250 plan; M=2000 needs stack_gb=40 and ~25 min on 5 threads) -> cr2_su2_m{1000,2000}_sw1_site20.struct.npz
+$R $D/CR2.SVP.FCIDUMP su2 1000 2 /tmp/cr2m1000b struct=1:20 stop_after=1:20 occ=$D/CR2.SVP.OCC dav_iter=2 nthreads=4 iprint=2 noise=1e-5,1e-5
+$R $D/CR2.SVP.FCIDUMP su2 2000 2 /tmp/cr2m2000 struct=1:20 stop_after=1:20 occ=$D/CR2.SVP.OCC dav_iter=2 nthreads=5 iprint=2 noise=1e-5,1e-5 stack_gb=40
 # the bundled 1D Hubbard L=16 file at M=500: the run converges in 4 sweeps (325 events, 60 site energies; 13 MB)
 mkdir -p chain_hubu2
 $R $D/HUBBARD-L16.FCIDUMP sz 500 6 ./chain_hubu2/hubc chain=5 nodelay=1 nocache=1 noise=0,0,0,0,0,0 tol=1e-12 iprint=0

@@ -147,26 +147,83 @@ def test_sum_mpo_four_ranks_energy(gpu):
     assert worst < 1e-7 and abs(e1[-1] - (-107.654122447525)) < 1e-7
 
 
+def _truncation_evidence(dm, fx):
+    """what the truncation log of a replayed chain must show for the replay to count as the reference's calculation:
+    (i) this loop's OWN choice of kept states (all eigenvalues of all sectors sorted, the largest k kept) gives the reference's
+    per-sector bond dimensions at every bond, except where the two choices differ inside a degenerate band at the cut
+    (kept and discarded weight equal to 1e-9 of the largest weight); (ii) the discarded weight of every truncated bond is the
+    reference's (SPECTRA lines of the fixture) to 2 %.  Returns (bonds, bonds with identical counts)"""
+    same = 0
+    for key, t in dm.trunc_log.items():
+        if t["same_counts"]:
+            same += 1
+        else:
+            assert t["band_rel_width"] < 1e-9, (key, t)
+        if "ref_discarded_weight" in t and t["ref_discarded_weight"] > 1e-12:
+            assert abs(t["discarded_weight"] - t["ref_discarded_weight"]) < 0.02 * t["ref_discarded_weight"], (key, t)
+    return len(dm.trunc_log), same
+
+
 def test_cr2_svp_chain_m30(gpu):
     """Cr2/SVP (the molecule of BASELINE configs[2-3]: 42 orbitals, D2h, SU2, bond dimensions from CR2.SVP.OCC) at M=30: the
-    539 events of two sweeps of one reference run (tests/golden/chain_cr2/cr2c.zip) replayed through all 82 sites.  At M=30
-    nearly every bond is truncated, and from the first truncated bond on (site 6) ties among the density-matrix weights are
-    broken differently than in the reference: the site energies before it are exact, the others agree to 5e-5 (4e-7
-    typical), and the final energy is NOT ABOVE the reference's (-2086.1190566236; here 2.7e-6 lower)."""
+    539 events of two sweeps of one reference run (tests/golden/chain_cr2/cr2c.zip) replayed through all 82 sites.
+    The site energies before the first truncated bond are exact; from site 6 on they agree to 5e-5 (4e-7 typical) and the
+    final energy is NOT ABOVE the reference's.  Why not closer (profiles/r03_cr2_m30_trunc_diag.txt): the choice of kept
+    states is the reference's at EVERY bond (_truncation_evidence), but the reference cuts at a weight of 1e-14
+    (DMRG::cutoff) — in a sweep from a random MPS the wavefunction has few significant weights, and most of the states it
+    keeps are eigenvectors of the NUMERICAL null space of the density matrix (weights 1e-14..1e-13, below the 1e-13 to which
+    Davidson converges psi).  Which vectors those are is decided by rounding, in the reference as here, and the next site's
+    variational space contains them."""
     from block2_preview_amd.sweep import DMRG, ChainFixture
 
     fx = ChainFixture(os.path.join(GOLDEN, "chain_cr2", "cr2c"))
     assert len(fx.events) == 539 and len(fx.ref_energy) == 82
     dm = DMRG(fx, "su2")
+    dm.check_truncation = True
     dm.init_environments()
     assert dm.n_sites == 42
     es = dm.sweep(0, True) + dm.sweep(1, False)
     assert fx.pos == len(fx.events)
     d = {k: abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items()}
-    print("Cr2 M=30: worst |dE| = %.2e, final %.10f (reference %.10f)" % (max(d.values()), min(es), fx.final_energy))
+    bonds, same = _truncation_evidence(dm, fx)
+    print("Cr2 M=30: worst |dE| = %.2e, final %.10f (reference %.10f); own choice of kept states = the fixture's at %d of %d bonds"
+          % (max(d.values()), min(es), fx.final_energy, same, bonds))
     assert all(d[(0, i)] < 1e-9 for i in range(6))
     assert max(d.values()) < 5e-5
     assert min(es) <= fx.final_energy + 1e-7 and abs(min(es) - fx.final_energy) < 1e-5
+    assert bonds == 80 and same >= 78
+    # the first site that leaves the reference follows a bond whose kept states reach down to the cutoff
+    first = min(k for k in sorted(d) if d[k] > 1e-9)
+    prev = (first[0], first[1] - 1)
+    assert dm.trunc_log[prev]["last_kept"] < 1e-12 * dm.trunc_log[prev]["w_max"]
+
+
+def test_cr2_svp_chain_m250_noisy_schedule(gpu):
+    """THE Cr2 gate at the bond dimension SURVEY 8d(i) names: Cr2/SVP SU2 M=250, the reference's noisy schedule (noises 1e-5,
+    1e-5, 0; ReducedPerturbative), three sweeps = 123 sites, 845 events (tests/golden/chain_cr2_m250_noisy/cr2n250.zip; the
+    reference needs 693 s for them on 3 threads, this loop 25 s).  Result: every site energy within 2e-5 Ha, the final energy
+    8.8e-6 BELOW the reference's -2086.4479795396 — NOT the 1e-6 of the north star, and the truncation log says why this is
+    the reference's own reproducibility, not an error of the path (profiles/r03_cr2_m250_noisy_trunc_diag.txt):
+      * the kept states are the reference's at 118 of 120 bonds and differ inside a tie (band 4e-12 of the largest weight) at
+        the other two; the discarded weights are the reference's to 1 %; the spectra agree to 1e-5;
+      * sites 0-5 (no truncation) agree to 3e-11; the first difference (1e-7, site 6) follows the first bond at which the
+        reference's cut-off of 1e-14 (DMRG::cutoff) decides the number of kept states: 139 of 188 states kept, the last
+        with weight 1.04e-14, the first discarded 0.99e-14 — eigenvalues of the numerical null space, whose eigenvectors
+        rounding decides.  Two runs of the REFERENCE that differ only in their thread count differ from each other in the
+        same way (profiles/r03_reference_reproducibility_cr2_m250.txt)."""
+    fx, dm, es = _noisy(gpu, os.path.join("chain_cr2_m250_noisy", "cr2n250"), "su2", 3, 82)
+    d = {k: abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items()}
+    bonds, same = _truncation_evidence(dm, fx)
+    print("Cr2 M=250 noisy: worst |dE| = %.2e, final %.10f (reference %.10f), kept states = the fixture's at %d of %d bonds" % (
+        max(d.values()), min(es), fx.final_energy, same, bonds))
+    assert len(fx.ref_energy) == 123 and dm.n_sites == 42
+    assert all(d[(0, i)] < 1e-9 for i in range(6))
+    assert max(d.values()) < 3e-5
+    assert min(es) <= fx.final_energy + 1e-6 and abs(min(es) - fx.final_energy) < 2e-5
+    assert bonds == 120 and same >= 115
+    first = min(k for k in sorted(d) if d[k] > 1e-9)
+    prev = (first[0], first[1] - 1)
+    assert dm.trunc_log[prev]["last_kept"] < 1e-12 * dm.trunc_log[prev]["w_max"]
 
 
 def _noisy(gpu, prefix, sym, n_sweeps, n_noisy_sites):
