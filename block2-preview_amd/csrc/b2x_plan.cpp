@@ -641,7 +641,7 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         // second (M=1000 -3 %, M=2000 -2 % on one box), plans with a real share of <= 3-fragment tiles keep the first
         // (uniform-M Cr2 M=1000: +3 % with 5).  Shares estimated from the pairs' row counts, MAC-weighted.
         {
-            double w3 = 0, w5 = 0, wt = 0;
+            double w3 = 0, w5 = 0, w7 = 0, wt = 0;
             for (const Component *c : big)
                 for (uint32_t wi = c->w_begin; wi < c->w_end; wi++) {
                     const b2x_pair &p = pairs[win[wi].pair];
@@ -656,6 +656,8 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
                                 w3 += ws;
                             else if (fr <= kGGMidFrags)
                                 w5 += ws;
+                            else if (fr >= 7)
+                                w7 += ws;
                         }
                     }
                 }
@@ -663,6 +665,20 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
             out.short_frags = sf_env == kGGShortFrags || sf_env == kGGMidFrags
                                   ? sf_env
                                   : (wt > 0 && w3 / wt < 0.25 && w5 / wt > 0.3 ? kGGMidFrags : kGGShortFrags);
+            if (pc.on)
+                fprintf(stderr, "[b2x plan] row-tile shares (MAC-weighted): <=3 frags %.3f, 4-5 %.3f, 6 %.3f, 7-8 %.3f\n", w3 / wt,
+                        w5 / wt, (wt - w3 - w5 - w7) / wt, w7 / wt);
+            // Tile-height cap.  Plans whose work sits in tiles of 4-6 row fragments rather than in full 8-fragment ones (the
+            // TRUE Cr2 structures at M=2000-4000: 34-60 % of the work in 7-8-fragment tiles, against 74 % for the x16 plan)
+            // run faster when NO tile is taller than 5 fragments: the whole plan then runs on the <= 168-VGPR instantiation
+            // at three waves per SIMD (true M=2000: +7 %, its x2: +3.5 %, x16: +-0; same-box sweeps in
+            // profiles/r03_tile_height_cap_true_structures.txt).  It requests more operand bytes (5-fragment tiles: 6.1 MAC
+            // per byte against 8), which costs nothing: the kernel does not wait for the fabric
+            // (profiles/r03_l2_window_probe.txt).  Plans with a real share of <= 3-fragment tiles keep the four-waves-per-SIMD
+            // class for them (true M=1000: -1.5 % with the cap).  B2X_MAX_UNITS overrides.
+            out.cap_units = (wt > 0 && w3 / wt < 0.25 && w7 / wt < 0.65) ? kGGMidFrags : 0;
+            if (out.cap_units && !(sf_env == kGGShortFrags || sf_env == kGGMidFrags))
+                out.short_frags = kGGMidFrags;
         }
         pc.lap("3 class estimates");
         const int short_frags = out.short_frags;
@@ -679,9 +695,10 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
         const bool use_narrow = narrow_env != 0 && TN == 64 && wsum > 0 && wn / wsum < narrow_w;
         out.short_narrow = use_narrow;
         const int short_rows = (use_narrow ? kGGNarrowFrags : short_frags) * kGGRowUnit;
-        static const int max_units_env = getenv("B2X_MAX_UNITS") ? atoi(getenv("B2X_MAX_UNITS")) : kGGTileM / kGGRowUnit; // (probe)
+        static const int max_units_env = getenv("B2X_MAX_UNITS") ? atoi(getenv("B2X_MAX_UNITS")) : 0; // (probe)
+        const int max_units = max_units_env > 0 ? max_units_env : (out.cap_units ? out.cap_units : kGGTileM / kGGRowUnit);
         auto row_cuts = [&](int total) -> const std::vector<int> & {
-            return use_narrow && total <= kGGShortFrags * kGGRowUnit ? unit_cuts_m(total, kGGNarrowFrags) : unit_cuts_m(total, max_units_env);
+            return use_narrow && total <= kGGShortFrags * kGGRowUnit ? unit_cuts_m(total, kGGNarrowFrags) : unit_cuts_m(total, max_units);
         };
         auto col_tile = [&](int rows) { return use_narrow && rows <= short_rows ? kGGNarrowN : TN; };
         // effective pairs of this path: an operator pre-sum (below) replaces the second operator of a merged pair by a

@@ -159,6 +159,7 @@ struct CompiledPlan {
     uint64_t scratch_elems = 0, gslab_elems = 0;
     bool fallback = false; // windows could not be segmented -> generic atomic kernel
     std::string fallback_reason;
+    int cap_units = 0; // tallest tile in row fragments when the compiler caps it below kGGTileM / 16 (0: no cap)
     int short_frags = kGGShortFrags; // tallest tile (row fragments) of the short class of this plan: kGGShortFrags or kGGMidFrags
     bool short_narrow = false; // the short tile class ([v[1], v[last]) of every stage) holds tiles of <= 32 x 32: 1-wave workgroups
     bool seg_scaled = false; // single-GEMM list: segments carry their own alpha (gg_kernel SCALED variant)
