@@ -6,9 +6,13 @@ executes 5–90 times per site inside Davidson (src/core/iterative_matrix_functi
 
 Workloads (--workload, config.workload in the output; all from plan structures the running reference recorded,
 operator blocks / psi filled uniform [0,1) on the device like Random::fill, src/core/utils.hpp:247-252):
-  cr2_m4000      (default; the configuration the BASELINE metric is quoted on) Cr2/SVP SU(2) mid-chain plan captured at
-                 M=250 (sweep 1, site 20) with every sector dimension x16 -> M=4000: 98 722 pairs, 20.7 TMAC, 73 GB
-  cr2_m2000      the same structure x8 -> M=2000 (BASELINE configs[2])
+  cr2_true_m4000 (default; the configuration the BASELINE metric is quoted on) Cr2/SVP SU(2) mid-chain plan captured from the
+                 reference at its TRUE M=2000 (sweep 1, site 20; the largest bond dimension the reference can be run at in
+                 the authoring container) with every sector dimension x2 -> M=4000: 249 495 pairs, 24.1 TMAC, 90 GB
+  cr2_true_m2000 / cr2_true_m1000   the reference's captures at M=2000 / M=1000 as they are
+  cr2_m4000      (the default of rounds 1-2) the M=250 capture x16 -> M=4000: 98 722 pairs, 20.7 TMAC, 73 GB; every dimension
+                 is a multiple of 16, i.e. of the MFMA fragment: no padding at all, which a real M=4000 structure has
+  cr2_m2000      the M=250 structure x8 -> M=2000 (BASELINE configs[2])
   h10_m500       H10/STO-6G SZ at its TRUE M=500 mid-chain structure (configs[1]): 8 276 pairs, 0.48 GMAC
   hubbard_m3000  1D Hubbard L=16 U/t=4 SZ at its TRUE M=3000 structure (configs[4]): 692 pairs, 54 GMAC
 With N GPUs the operator terms of the plan are sharded sum-MPO style (every rank owns a subset of the left-operator
@@ -113,6 +117,10 @@ def sweep_leg(args):
     capi.device_init(0)
     names = sorted(SWEEP_CHAINS) if args.sweep == "all" else [x for x in args.sweep.split(",") if x]
     res = {}
+    # the reference's own clock for the same schedules (tests/golden/make_ref_times.sh: block2 on 8 threads of the authoring
+    # container, quiet machine, no event dumping; "default" = block2's default contraction settings)
+    rt_file = os.path.join(GOLD, "ref_sweep_times.json")
+    ref_times = json.load(open(rt_file)) if os.path.exists(rt_file) else {}
     for name in names:
         if name not in SWEEP_CHAINS:
             raise SystemExit("unknown chain %r (have: %s)" % (name, ", ".join(sorted(SWEEP_CHAINS))))
@@ -149,10 +157,11 @@ def sweep_leg(args):
                        "Tprt": round(tm.get("noise.record", 0) + tm.get("noise.device", 0), 4),
                        "Tblk": round(tm.get("block", 0) + tm.get("rotate", 0) + tm.get("transform", 0) + tm.get("assign", 0), 4),
                        "Tsplt": tm.get("split", 0.0)}
-                rt = fx.ref_sweep_time.get(isw)
-                if rt:
+                rts = ref_times.get(name, {}).get("default", {}).get("sweeps", [])
+                if isw < len(rts):
+                    rt = rts[isw]
                     row["reference_cpu"] = {"wall_s": rt[0], "Teff": rt[1], "Teig": rt[2], "Tprt": rt[3], "Tblk": rt[4],
-                                            "Tsplt": rt[7], "threads": 8}
+                                            "Tsplt": rt[7], "threads": 8, "settings": "block2 defaults"}
                     row["speedup_vs_reference_cpu"] = round(rt[0] / wall, 3)
                 sweeps.append(row)
             assert fx.pos == len(fx.events), "the chain was not replayed to its end"
@@ -172,7 +181,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cr2_m4000", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cr2_true_m4000", choices=sorted(WORKLOADS))
     ap.add_argument("--scale", type=int, default=0, help="override the sector-dimension multiplier of the workload")
     ap.add_argument("--struct", default="", help="override the plan structure file of the workload")
     ap.add_argument("--cpu-gmac", type=float, default=0.0, help="MAC budget of the cpu_baseline sample (0 = auto)")
@@ -750,7 +759,8 @@ def main():
             del arena_t, psi_t, sigma_t
             torch.cuda.empty_cache()
             try:
-                out["site_step_ms"] = site_step(scale, M, dt / args.steps * 1e3, recycled_s, dev, log)
+                # (the noise / rotation / blocking lists are the M=250 captures scaled to this M, whatever the H.psi structure)
+                out["site_step_ms"] = site_step(max(1, M // 250), M, dt / args.steps * 1e3, recycled_s, dev, log)
                 out["site_step_ms"]["hpsi_plan_create_first_ms"] = round(compile_s * 1e3, 1)
                 ss = out["site_step_ms"]
                 ss["hpsi_plan_cached_ms"] = round(cached_s * 1e3, 1)

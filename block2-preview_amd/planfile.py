@@ -224,3 +224,50 @@ def mps_tensor_filename(save_dir, prefix, tag, i):
     """scratch file of MPS tensor i (MPS::get_filename, src/dmrg/mps.hpp): <save_dir>/<prefix>.MPS.<tag>.<i>; i = -1 holds
     the canonical form and center"""
     return "%s/%s.MPS.%s.%d" % (save_dir, prefix, tag, i)
+
+
+def read_partition_file(fn, fp_prec=None, fp_chunk=1024):
+    """content of a partition file of MovingEnvironment (frame_->save_data(1, get_left/right_partition_filename(i)),
+    src/dmrg/moving_environment.hpp:428-440; DataFrame::save_data_to / load_data_from, src/core/allocator.hpp:518-530, 580-592):
+    the frame's two stacks as they stand —
+        size_t  words used of the integer stack      size_t  elements used of the double stack
+        uint32 x that many   (the SparseMatrixInfo arrays of the block's operators, in allocation order)
+        double x that many   (the renormalised operator blocks, in allocation order; with DataFrame::fp_codec set: the
+                              FPCodec::write_array stream of them instead, src/core/fp_codec.hpp)
+    Returns (integer stack, double stack)."""
+    import struct
+
+    raw = open(fn, "rb").read()
+    if len(raw) < 16:
+        raise ValueError("%s: too short for a partition file" % fn)
+    iused, dused = struct.unpack_from("<QQ", raw, 0)
+    off = 16 + 4 * iused
+    if off > len(raw):
+        raise ValueError("%s: integer stack of %d words does not fit the file" % (fn, iused))
+    istack = np.frombuffer(raw, np.uint32, iused, 16).copy()
+    if fp_prec is None:
+        if len(raw) != off + 8 * dused:
+            raise ValueError("%s: %d bytes, header says %d" % (fn, len(raw), off + 8 * dused))
+        dstack = np.frombuffer(raw, np.float64, dused, off).copy()
+    else:
+        from . import b2x_host
+
+        dstack = np.asarray(b2x_host.fpcodec_decode(raw[off:], int(dused)), np.float64)
+    return istack, dstack
+
+
+def write_partition_file(fn, istack, dstack, fp_prec=None, fp_chunk=1024):
+    """the inverse of read_partition_file: byte-identical to what the reference writes for the same stacks"""
+    import struct
+
+    istack = np.ascontiguousarray(istack, np.uint32)
+    dstack = np.ascontiguousarray(dstack, np.float64)
+    with open(fn, "wb") as f:
+        f.write(struct.pack("<QQ", istack.size, dstack.size))
+        f.write(istack.tobytes())
+        if fp_prec is None:
+            f.write(dstack.tobytes())
+        else:
+            from . import b2x_host
+
+            f.write(bytes(b2x_host.fpcodec_encode(dstack, fp_prec, fp_chunk)))

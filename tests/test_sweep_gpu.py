@@ -152,7 +152,9 @@ def _truncation_evidence(dm, fx):
     (i) this loop's OWN choice of kept states (all eigenvalues of all sectors sorted, the largest k kept) gives the reference's
     per-sector bond dimensions at every bond, except where the two choices differ inside a degenerate band at the cut
     (kept and discarded weight equal to 1e-9 of the largest weight); (ii) the discarded weight of every truncated bond is the
-    reference's (SPECTRA lines of the fixture) to 2 %.  Returns (bonds, bonds with identical counts)"""
+    reference's (SPECTRA lines of the fixture) to 10 % (once the two runs have drifted apart by 1e-6 in energy their
+    wavefunctions, hence their spectra, differ at that level; typical agreement 0.1-2 %).  Returns (bonds, bonds with
+    identical counts)"""
     same = 0
     for key, t in dm.trunc_log.items():
         if t["same_counts"]:
@@ -160,7 +162,7 @@ def _truncation_evidence(dm, fx):
         else:
             assert t["band_rel_width"] < 1e-9, (key, t)
         if "ref_discarded_weight" in t and t["ref_discarded_weight"] > 1e-12:
-            assert abs(t["discarded_weight"] - t["ref_discarded_weight"]) < 0.02 * t["ref_discarded_weight"], (key, t)
+            assert abs(t["discarded_weight"] - t["ref_discarded_weight"]) < 0.1 * t["ref_discarded_weight"], (key, t)
     return len(dm.trunc_log), same
 
 
@@ -271,3 +273,34 @@ def test_h10_noisy_schedule_chain(gpu):
     assert abs(min(es) - (-5.424385376237)) < 1e-7
     noisy = [v for k, v in dm.trunc_log.items() if k[0] < 2 and k != first and "spectrum_max_abs_diff" in v]
     assert len(noisy) == 15 and max(v["spectrum_max_abs_diff"] for v in noisy) < 2e-7
+
+
+def test_partition_file_content_matches_the_device_blocks(gpu):
+    """what the reference wrote into its partition files IS what this loop holds in HBM: N2/STO-3G SU2 M=60, two sweeps, run
+    with block2's default stack allocation and its scratch directory kept (tests/golden/part_n2su2: the chain + the files
+    F0.PART.DMRG.RIGHT.0-7).  The renormalised right block of sites j.. on the device (sweep.DMRG.R[j]) and the double stack of
+    RIGHT.(j-2) hold the same operators in the same layout; their numbers differ by the gauge of the MPS (the sign / rotation
+    of the kept eigenvectors), which the Frobenius norm of every operator does not see: equal to 1e-3 relative, operator by
+    operator (1e-4 observed: at M=60 some kept states lie in the numerical null space of the density matrix, and which
+    vectors those are differs between the two runs; a wrong layout or a wrong operator is off by O(1))."""
+    from block2_preview_amd.planfile import read_partition_file
+    from block2_preview_amd.sweep import DMRG, ChainFixture
+
+    fx = ChainFixture(os.path.join(GOLDEN, "part_n2su2", "n2p"))
+    dm = DMRG(fx, "su2")
+    dm.init_environments()
+    dm.sweep(0, True), dm.sweep(1, False)
+    assert fx.pos == len(fx.events)
+    assert max(abs(dm.energies[k] - e) for k, e in fx.ref_energy.items()) < 1e-7
+    compared = 0
+    for j in range(2, dm.n_sites):
+        _, dst = read_partition_file(os.path.join(GOLDEN, "part_n2su2", "F0.PART.DMRG.RIGHT.%d" % (j - 2)))
+        t = dm.R[j]
+        if t.n != len(dst):
+            continue  # (the block at the NC -> CN switch: the reference's stack holds a subset, tests/test_disk_format.py)
+        dev = t.buf.download()
+        for key, (off, ln) in t.layout.items():
+            a, b = np.linalg.norm(dev[off:off + ln]), np.linalg.norm(dst[off:off + ln])
+            assert abs(a - b) <= 1e-3 * max(1e-3, b), (j, hex(key), a, b)
+            compared += 1
+    assert compared > 100

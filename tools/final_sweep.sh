@@ -5,8 +5,8 @@ R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/final
 mkdir -p $out
 cd $R
-for w in cr2_m250 cr2_m500 cr2_m1000 cr2_m2000 cr2_m4000 h10_m500 hubbard_m3000 cr2_noocc_m1000 cr2_noocc_m4000; do
-  timeout -k 10 400 python bench.py --workload $w --steps 20 --warmup 5 --no-cpu --site-step 0 > $out/$w.json 2> $out/$w.err || echo "bench $w failed"
+for w in cr2_m250 cr2_m500 cr2_m1000 cr2_m2000 cr2_m4000 cr2_true_m1000 cr2_true_m2000 cr2_true_m4000 h10_m500 hubbard_m3000 cr2_noocc_m1000 cr2_noocc_m4000; do
+  timeout -k 10 400 python bench.py --workload $w --steps 10 --warmup 3 --no-cpu --site-step 0 > $out/$w.json 2> $out/$w.err || echo "bench $w failed"
   python - $out/$w.json <<'PY'
 import json,sys
 j=json.load(open(sys.argv[1])); r=j["roofline"]

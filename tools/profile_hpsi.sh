@@ -1,11 +1,12 @@
 #!/bin/bash
-# Round-2 evidence, one directory per workload under gpurun_out/prof_r02/ (copy the summaries into profiles/ afterwards):
+# Per-round evidence (ROUND=r03 by default), one directory per workload under gpurun_out/prof_$ROUND/ (copy the summaries into profiles/ afterwards):
 #   rocprofv3 --kernel-trace --stats over the bench command of the workload, then separate --pmc FETCH_SIZE / WRITE_SIZE
 #   passes over tools/pmc_probe.py <workload> (one H.psi + the calibration kernel)
 R=$GRAFT_REPO_ROOT
+ROUND=${ROUND:-r03}
 cd /tmp && export TMPDIR=/tmp
 for w in "$@"; do
-  out=$R/gpurun_out/prof_r02/$w
+  out=$R/gpurun_out/prof_$ROUND/$w
   mkdir -p $out
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o t -- python3 $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu > $out/bench_under_rocprof.json 2> $out/bench_under_rocprof.err || { echo "trace $w failed"; exit 1; }
   cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
