@@ -107,3 +107,8 @@ $R $D/N2.STO3G.FCIDUMP su2 60 2 ./x stop_after=1:4 iprint=0 scratch=/tmp/b2x_lis
 # the Cr2 site-20 plan WITHOUT occupation-guided initial bond dimensions (what SURVEY.md counted: 400-570 k pairs) ->
 # cr2_su2_m250_noocc_sw1_site20.struct.npz
 $R $D/CR2.SVP.FCIDUMP su2 250 2 ./cr2noocc struct=1:20 stop_after=1:20 noise=1e-5,1e-5 iprint=0
+# partition-file content: the files the reference writes while building the initial environments with its default
+# stack allocation (main_stack=1); the run is left at the first site, so its scratch directory still holds them -> part_n2su2/
+mkdir -p part_n2su2 /tmp/b2x_partchain
+$R $D/N2.STO3G.FCIDUMP su2 200 2 /tmp/b2x_partchain/n2p chain=0 nodelay=1 nocache=1 noise=0,0 tol=1e-12 dav_thrd=1e-13 iprint=0 main_stack=1 stop_after=0:0 scratch=/tmp/b2x_part nthreads=2
+cp /tmp/b2x_part/F0.PART.DMRG.RIGHT.* part_n2su2/ && zipchain /tmp/b2x_partchain n2p && cp /tmp/b2x_partchain/n2p.zip part_n2su2/

@@ -145,19 +145,18 @@ PART = sorted(glob.glob(os.path.join(GOLDEN, "part_n2su2", "F0.PART.DMRG.RIGHT.*
 def test_partition_file_content_round_trip(built, tmp_path):
     """partition-file CONTENT (MovingEnvironment: frame_->save_data(1, get_right_partition_filename(i)),
     src/dmrg/moving_environment.hpp:428-440; DataFrame::save_data_to, src/core/allocator.hpp:580-592): the files the reference
-    left in its scratch directory after two sweeps of N2/STO-3G SU2 M=60 with its default stack allocation (operators on the
-    frame stack) are read into their two stacks and written back byte for byte; the double stack of RIGHT.i is the
-    renormalised right block of sites i+2.. — its length is the length of the rotated block in the event chain of the same run
-    (tests/golden/part_n2su2/n2p.zip), operator by operator"""
-    from block2_preview_amd.planfile import read_partition_file, write_partition_file
+    left in its scratch directory after building the initial environments of N2/STO-3G SU2 M=200 with its default stack
+    allocation (operators on the frame stack; the run stops at the first site) are read into their two stacks and written
+    back byte for byte; the double stack of RIGHT.i is the renormalised right block of sites i+2.. — its length is the
+    length of that block in the event chain of the same run (tests/golden/part_n2su2/n2p.zip)"""
+    from block2_preview_amd.planfile import read_arrays, read_partition_file, write_partition_file
     from block2_preview_amd.sweep import ChainFixture
 
     assert len(PART) == 8
     fx = ChainFixture(os.path.join(GOLDEN, "part_n2su2", "n2p"))
-    last_rrot = set()  # lengths of the right blocks of the run's last sweep: rotation (+ the operator sums formed inside
-    from block2_preview_amd.planfile import read_arrays  # the rotated block by the NC -> CN transform events that follow it)
-    for pos, (n, kind, fn) in enumerate(fx.events):
-        if kind == "rrot" and fx.meta[n][1] == 1:
+    last_rrot = set()  # lengths of the right blocks: rotation (+ the operator sums the NC -> CN transform events that follow
+    for pos, (n, kind, fn) in enumerate(fx.events):  # it form inside the rotated block)
+        if kind == "rrot":
             total = int(read_arrays(fn)["meta"][6])
             for n2, k2, fn2 in fx.events[pos + 1:]:
                 if k2 not in ("rntr", "rint"):
@@ -172,8 +171,8 @@ def test_partition_file_content_round_trip(built, tmp_path):
         assert open(out, "rb").read() == open(fn, "rb").read()
         matched += len(dst) in last_rrot
         assert np.isfinite(dst).all() and np.abs(dst).max() > 0
-    # (7 of the 8 blocks have exactly the chain's length; the block at the NC -> CN switch of the MPO also holds, in the
-    #  reference's stack, only the operators the next blocking reads: 2 043 elements against the chain's 2 573)
+    # (7 of the 8 blocks have exactly the chain's length; the block at the NC -> CN switch of the MPO holds, in the
+    #  reference's stack, only the operators the next blocking reads: 7 360 elements against the chain's 9 244)
     assert matched >= 7
     # compressed storage of the same stacks: coded and decoded through the FPCodec mirror within its precision
     ist, dst = read_partition_file(PART[2])
