@@ -225,8 +225,27 @@ def test_edge_cases(gpu):
     plan.close(), ar.close(), arena.close()
 
 
-@pytest.mark.parametrize("scale", [8, 16], ids=["cr2_m2000", "cr2_m4000"])
-def test_full_size_cr2_properties(gpu, scale):
+def test_true_cr2_m1000_structure_against_the_oracle(gpu):
+    """the plan the reference records for Cr2/SVP SU2 at its TRUE M=1000 (sweep 1, site 20: 206 245 pairs, 371 GMAC, 5.2 GB of
+    operators; tests/golden/cr2_su2_m1000_sw1_site20.struct.npz), synthetic data: the oracle replays the FULL plan on the
+    host cores, so parity at this size is direct.  Default compilation (association, shared products, sum pass) and the
+    reference's order pair by pair."""
+    pf = _struct("cr2_su2_m1000_sw1_site20.struct.npz")
+    assert len(pf.pairs) == 206245 and pf.macs == 371375030711
+    pf = fill_plan(pf, 33)
+    ref = np.zeros(pf.sigma_len)
+    oracle.replay(pf.pairs, pf.arena, pf.psi, ref, 1.0, 16)
+    sig, st = _run(gpu, pf)
+    assert st["fallback"] == 0 and st["macs_issued"] > 0 and st["n_shared_products"] > 0 and st["n_flipped"] > 0
+    assert _close(sig, ref), st
+    sig2, st2 = _run(gpu, pf, keep_order=1)
+    assert st2["macs_executed"] == pf.macs and _close(sig2, ref), st2
+
+
+@pytest.mark.parametrize("sfile,scale", [("cr2_su2_m250_sw1_site20.struct.npz", 8), ("cr2_su2_m250_sw1_site20.struct.npz", 16),
+                                         ("cr2_su2_m2000_sw1_site20.struct.npz", 1), ("cr2_su2_m2000_sw1_site20.struct.npz", 2)],
+                         ids=["cr2_m2000", "cr2_m4000", "cr2_true_m2000", "cr2_true_m4000"])
+def test_full_size_cr2_properties(gpu, sfile, scale):
     """BASELINE sizes of the Cr2/SVP SU2 mid-chain plan: x8 -> M=2000 (configs[2]: 2.6 TMAC, 9.2 GB of operators) and
     x16 -> M=4000 (configs[3], the bench workload: 98 722 pairs, 20.7 TMAC, 73 GB of operators).  The oracle cannot visit
     these, so the MFMA path is checked through size-independent properties: linearity in psi, bitwise repeatability,
@@ -236,8 +255,8 @@ def test_full_size_cr2_properties(gpu, scale):
 
     from block2_preview_amd.planfile import read_struct_npz
 
-    base = read_struct_npz(os.path.join(os.path.dirname(FILES[0]), "cr2_su2_m250_sw1_site20.struct.npz"))
-    full = synth.scale_plan(base, scale)
+    base = read_struct_npz(os.path.join(os.path.dirname(FILES[0]), sfile))  # (cr2_true_*: the reference's capture at its
+    full = synth.scale_plan(base, scale) if scale > 1 else base              #  TRUE M=2000; x2 = the default bench workload)
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev)
     g.manual_seed(5)
@@ -263,6 +282,7 @@ def test_full_size_cr2_properties(gpu, scale):
     assert float((hz - (0.3 * hx - 1.7 * hy)).abs().max()) <= 1e-11 * scale
     assert torch.equal(apply(x), hx)  # fixed summation order
     assert plan.stats["macs_executed"] < 0.7 * full.macs  # association / sharing / sums of products
+    assert plan.stats["n_merged_groups"] > 0 and plan.stats["n_shared_products"] > 0 and plan.stats["n_flipped"] > 0
     plan.close()
     # the same plan replayed pair by pair in the reference's order of operations
     ref_order = gpu.Plan(arena, full.pairs, full.psi_len, full.sigma_len, keep_order=1)
