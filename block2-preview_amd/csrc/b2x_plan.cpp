@@ -576,7 +576,12 @@ int compile_plan(size_t n_pairs, const b2x_pair *pairs, size_t psi_len, size_t s
     const bool forced = opt && opt->item_macs > 0;
     const double item_cost = forced ? (double)opt->item_macs : std::max((double)total_cost / 10240.0, 131072.0);
     // (upper bound 3e7: at M=1000 6e7 left too few items per launch, 12.6 -> 11.5 ms; no difference at M >= 2000)
-    const double step_item_cost = forced ? (double)opt->item_macs : std::min(3.0e7, std::max(2.0e6, gg_macs_total / 4096.0));
+    // (plans below ~1.5 GMAC — H10/STO-6G at M=500: 0.48 GMAC in 50 psi' tiles — are latency-bound launches of a few hundred
+    //  items that walk ~50 segments each: items of 3e5 instead of 2e6 slot units fill the chip, stage 1 0.123 -> 0.084 ms and the
+    //  whole H.psi 0.132 -> 0.113 ms (more partial slabs for the reduce); above that size smaller items lose to the reduce:
+    //  profiles/r03_item_size_small_plans_ab.txt)
+    const double step_item_lb = gg_macs_total < 1.5e9 ? 3.0e5 : 2.0e6;
+    const double step_item_cost = forced ? (double)opt->item_macs : std::min(3.0e7, std::max(step_item_lb, gg_macs_total / 4096.0));
     uint64_t slab = 0;
     for (size_t t = 0; t < htiles.size(); t++) {
         HostTile &ht = htiles[t];
