@@ -35,6 +35,7 @@
  *   occ=<file>   nthreads=<n>   seed=<n>   noise=<a,b,c>   tol=<x>   dav_iter=<n>  pg=<d2h|c1>
  *   stack_gb=<n>  main_stack=1  keep_part=1   size of the double stack; operators on the frame stack (block2's default);
  *                                            partition files left in the scratch directory
+ *   cutoff=<x>                               DMRG::cutoff (smallest density-matrix weight that may be kept; default 1e-14)
  *   dav_thrd=<x>                             Davidson threshold of EVERY sweep (the default loosens it to noise / 10 in noisy sweeps)
  *   prefactors=1                             (with para=) also write ParallelRuleSimple::index_prefactor of every (i,j), (i,j,k,l)
  *   para=i|ij                                sum-MPO parallel rule (ParallelRuleSimple I / IJ); under mpirun with the
@@ -1473,6 +1474,8 @@ int run(const string &fd, int M, int n_sweeps, const string &prefix, map<string,
     dmrg->noise_type = NoiseTypes::ReducedPerturbative;
     dmrg->decomp_type = DecompositionTypes::DensityMatrix;
     dmrg->davidson_soft_max_iter = kv.count("dav_iter") ? Parsing::to_int(kv["dav_iter"]) : 4000;
+    if (kv.count("cutoff")) // DMRG::cutoff: density-matrix weights below it are never kept (default 1e-14)
+        dmrg->cutoff = Parsing::to_double(kv["cutoff"]);
     if (kv.count("dav_thrd")) // (default: noise * 0.1 in a noisy sweep, tol * 0.1 otherwise, sweep_algorithm.hpp:3038-3047)
         dmrg->davidson_conv_thrds = vector<double>(max(n_sweeps, 1), Parsing::to_double(kv["dav_thrd"]));
     dumper->dmrg = dmrg.get();

@@ -81,11 +81,16 @@ zipchain() { (cd $1 && python3 -c "import zipfile,glob,os; p='$2'; z=zipfile.Zip
 mkdir -p chain_cr2 /tmp/b2x_cr2c
 $R $D/CR2.SVP.FCIDUMP su2 30 2 /tmp/b2x_cr2c/cr2c chain=1 nodelay=1 nocache=1 noise=0,0 tol=1e-12 dav_thrd=1e-13 spectra=1 iprint=0 occ=$D/CR2.SVP.OCC
 zipchain /tmp/b2x_cr2c cr2c && cp /tmp/b2x_cr2c/cr2c.zip chain_cr2/
-# THE Cr2 gate: M=250, the reference's noisy schedule, three sweeps: 845 events -> chain_cr2_m250_noisy/cr2n250.zip
-# (693 s on 3 threads here).  The noise-free variant (noise=0,0; 541 events) is the input of profiles/r03_cr2_m250_noise_free_trunc_diag.txt.
-mkdir -p chain_cr2_m250_noisy /tmp/b2x_cr2n250
-$R $D/CR2.SVP.FCIDUMP su2 250 3 /tmp/b2x_cr2n250/cr2n250 chain=2 nodelay=1 nocache=1 noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-13 spectra=1 iprint=1 occ=$D/CR2.SVP.OCC nthreads=3
-zipchain /tmp/b2x_cr2n250 cr2n250 && cp /tmp/b2x_cr2n250/cr2n250.zip chain_cr2_m250_noisy/
+# THE Cr2 gate: M=250, the reference's noisy schedule, three sweeps, with a cut-off of 1e-9 on the kept
+# density-matrix weights (DMRG::cutoff) and Davidson converged to 1e-18: 845 events -> chain_cr2_m250_cut9/cr2g.zip (74 s on 8 threads)
+mkdir -p chain_cr2_m250_cut9 /tmp/b2x_cr2g
+$R $D/CR2.SVP.FCIDUMP su2 250 3 /tmp/b2x_cr2g/cr2g chain=2 nodelay=1 nocache=1 noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-18 cutoff=1e-9 spectra=1 iprint=0 occ=$D/CR2.SVP.OCC nthreads=8
+zipchain /tmp/b2x_cr2g cr2g && cp /tmp/b2x_cr2g/cr2g.zip chain_cr2_m250_cut9/
+# The same WITHOUT the cut-off (block2's default 1e-14) and dav_thrd=1e-13 is ill-posed — kept states reach into the numerical null
+# space of the density matrix: the inputs of profiles/r03_cr2_m250_noisy_trunc_diag.txt (noise=1e-5,1e-5,0; 693 s on 3 threads),
+# r03_cr2_m250_noise_free_trunc_diag.txt (noise=0,0) and r03_reference_reproducibility_cr2_m250.txt (nthreads=8 / 5 / 3, no chain=);
+# those chains are not committed (2 x 28 MB).
+# $R $D/CR2.SVP.FCIDUMP su2 250 3 /tmp/b2x_cr2n250/cr2n250 chain=2 nodelay=1 nocache=1 noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-13 spectra=1 iprint=1 occ=$D/CR2.SVP.OCC nthreads=3
 # noisy schedules on N2 and H10 (noises 1e-5, 1e-5, 0: perturbative noise -> perturbed density matrix -> split in the chain)
 mkdir -p chain_n2su2_noisy chain_h10sz_noisy
 $R $D/N2.STO3G.FCIDUMP su2 200 3 ./chain_n2su2_noisy/n2n chain=2 nodelay=1 nocache=1 noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-13 iprint=0 spectra=1 nthreads=2

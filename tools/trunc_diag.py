@@ -2,7 +2,7 @@
 """Where does a replayed chain leave the reference's energies, and is it a tie at the truncation?  Runs a chain fixture
 through sweep.DMRG with check_truncation: per site |dE|, whether this loop's own global choice of kept states gives the
 fixture's per-sector bond dimensions, the gap between the last kept and the first discarded density-matrix weight, and the
-distance of the whole spectrum from the one the reference truncated (SPECTRA lines).  usage: trunc_diag.py <prefix> <su2|sz> <n_sweeps>"""
+distance of the whole spectrum from the one the reference truncated (SPECTRA lines).  usage: trunc_diag.py <prefix> <su2|sz> <n_sweeps> [Davidson threshold, default 1e-13]"""
 import os
 import sys
 
@@ -13,7 +13,7 @@ from block2_preview_amd.sweep import DMRG, ChainFixture  # noqa: E402
 prefix, sym, n_sw = sys.argv[1], sys.argv[2], int(sys.argv[3])
 capi.device_init(0)
 fx = ChainFixture(prefix)
-dm = DMRG(fx, sym)
+dm = DMRG(fx, sym, conv_thrd=float(sys.argv[4]) if len(sys.argv) > 4 else 1e-13)
 dm.check_truncation = True
 dm.init_environments()
 for isw in range(n_sw):
