@@ -100,6 +100,7 @@ SWEEP_CHAINS = {
     "hubbard_m500": ("chain_hubu2/hubc", "sz", 4, "1D Hubbard L=16 U/t=2 (bundled FCIDUMP) SZ M=500, sweeps 0-3, no noise"),
     "cr2_m30": ("chain_cr2/cr2c", "su2", 2, "Cr2/SVP SU2 M=30, sweeps 0-1, no noise"),
     "cr2_m250": ("chain_cr2_m250_cut9/cr2g", "su2", 3, "Cr2/SVP SU2 M=250 (SURVEY 8d(i)), noises 1e-5, 1e-5, 0, cutoff 1e-9, Davidson 1e-18 (the energy-gate chain)"),
+    "cr2_m500": ("chain_cr2_m500_cut9/cr2h", "su2", 2, "Cr2/SVP SU2 M=500, noises 1e-5, 0, cutoff 1e-9, Davidson 1e-18 (the M=500 energy-gate chain)"),
     "n2_noisy": ("chain_n2su2_noisy/n2n", "su2", 3, "N2/STO-3G SU2 M=200, noises 1e-5, 1e-5, 0 (perturbative noise on)"),
     "h10_noisy": ("chain_h10sz_noisy/h10n", "sz", 3, "H10/STO-6G SZ M=500, noises 1e-5, 1e-5, 0 (perturbative noise on)"),
 }
@@ -133,7 +134,7 @@ def sweep_leg(args):
             if rep == 0:
                 capi.plan_cache_clear()
             fx = ChainFixture(path)
-            dm = DMRG(fx, sym, conv_thrd=1e-18 if name == "cr2_m250" else 1e-13)  # (the thresholds the chains were recorded with)
+            dm = DMRG(fx, sym, conv_thrd=1e-18 if name in ("cr2_m250", "cr2_m500") else 1e-13)  # (the thresholds the chains were recorded with)
             t0 = time.perf_counter()
             dm.init_environments()
             capi.device_sync()

@@ -86,6 +86,10 @@ zipchain /tmp/b2x_cr2c cr2c && cp /tmp/b2x_cr2c/cr2c.zip chain_cr2/
 mkdir -p chain_cr2_m250_cut9 /tmp/b2x_cr2g
 $R $D/CR2.SVP.FCIDUMP su2 250 3 /tmp/b2x_cr2g/cr2g chain=2 nodelay=1 nocache=1 noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-18 cutoff=1e-9 spectra=1 iprint=0 occ=$D/CR2.SVP.OCC nthreads=8
 zipchain /tmp/b2x_cr2g cr2g && cp /tmp/b2x_cr2g/cr2g.zip chain_cr2_m250_cut9/
+# ... and at M=500 (two sweeps: one noisy, one noise-free; 582 events, 154 s on 8 threads) -> chain_cr2_m500_cut9/cr2h.zip
+mkdir -p chain_cr2_m500_cut9 /tmp/b2x_cr2h
+$R $D/CR2.SVP.FCIDUMP su2 500 2 /tmp/b2x_cr2h/cr2h chain=1 nodelay=1 nocache=1 noise=1e-5,0 tol=1e-12 dav_thrd=1e-18 cutoff=1e-9 spectra=1 iprint=0 occ=$D/CR2.SVP.OCC nthreads=8
+zipchain /tmp/b2x_cr2h cr2h && cp /tmp/b2x_cr2h/cr2h.zip chain_cr2_m500_cut9/
 # The same WITHOUT the cut-off (block2's default 1e-14) and dav_thrd=1e-13 is ill-posed — kept states reach into the numerical null
 # space of the density matrix: the inputs of profiles/r03_cr2_m250_noisy_trunc_diag.txt (noise=1e-5,1e-5,0; 693 s on 3 threads),
 # r03_cr2_m250_noise_free_trunc_diag.txt (noise=0,0) and r03_reference_reproducibility_cr2_m250.txt (nthreads=8 / 5 / 3, no chain=);

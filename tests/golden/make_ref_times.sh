@@ -24,6 +24,7 @@ OUT=$T/n2n;  run n2_noisy     $D/N2.STO3G.FCIDUMP su2 200 3 $OUT noise=1e-5,1e-5
 OUT=$T/h10n; run h10_noisy    $D/H10.STO6G.R1.8.FCIDUMP sz 500 3 $OUT noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-13
 OUT=$T/cr2s; run cr2_m30      $D/CR2.SVP.FCIDUMP su2 30 2 $OUT noise=0,0 tol=1e-12 dav_thrd=1e-13 occ=$D/CR2.SVP.OCC
 [ -n "$SKIP_CR2_M250" ] || { OUT=$T/cr2;  run cr2_m250     $D/CR2.SVP.FCIDUMP su2 250 3 $OUT noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-18 cutoff=1e-9 occ=$D/CR2.SVP.OCC; }
+[ -n "$SKIP_CR2_M250" ] || { OUT=$T/cr2h; run cr2_m500 $D/CR2.SVP.FCIDUMP su2 500 2 $OUT noise=1e-5,0 tol=1e-12 dav_thrd=1e-18 cutoff=1e-9 occ=$D/CR2.SVP.OCC; }
 python3 - <<'PY'
 import glob, json, os
 T = "/tmp/b2x_ref_times"

@@ -225,6 +225,21 @@ def test_cr2_svp_m250_energy_gate(gpu):
     assert bonds == 120 and same == 120 and spec < 1e-6
 
 
+def test_cr2_svp_m500_energy_gate(gpu):
+    """the same gate at M=500 ("GPU path vs true reference at M=250 and M=500"): Cr2/SVP SU2 M=500, noises 1e-5, 0
+    (one noisy and one noise-free sweep: 82 sites, 582 events, tests/golden/chain_cr2_m500_cut9/cr2h.zip), cutoff 1e-9, Davidson
+    1e-18.  Every site energy to 1e-7 (1.1e-8 measured), the final energy -2086.2887243370 to 1e-7 (1.4e-9 measured), the
+    reference's kept states at every bond.  (The reference needs 160 + 22 s for the two sweeps on 8 threads, this loop 12 s.)"""
+    fx, dm, es = _noisy(gpu, os.path.join("chain_cr2_m500_cut9", "cr2h"), "su2", 2, 41, conv_thrd=1e-18)
+    d = {k: abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items()}
+    bonds, same = _truncation_evidence(dm, fx)
+    print("Cr2 M=500 gate: worst |dE| = %.2e over %d sites, final %.10f (reference %.10f), kept states = the fixture's at %d of %d bonds"
+          % (max(d.values()), len(d), min(es), fx.final_energy, same, bonds))
+    assert len(fx.ref_energy) == 82 and dm.n_sites == 42
+    assert max(d.values()) < 1e-7 and abs(min(es) - fx.final_energy) < 1e-7
+    assert bonds == 80 and same == 80
+
+
 def _noisy(gpu, prefix, sym, n_sweeps, n_noisy_sites, conv_thrd=1e-13):
     from block2_preview_amd.sweep import DMRG, ChainFixture
 
