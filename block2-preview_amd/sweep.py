@@ -68,12 +68,22 @@ class ChainFixture:
                 self.ref_total_time = float(t[1])
         self.pos = 0
 
+    def preload(self):
+        """parse every event file now (block2 holds its MPO and infos in memory; a timed replay should not read them from
+        disk inside the clock)"""
+        self._mem = {n: read_arrays(fn) for n, _, fn in self.events}
+        return self
+
+    def _arrays(self, n, fn):
+        mem = getattr(self, "_mem", None)
+        return dict(mem[n]) if mem is not None and n in mem else read_arrays(fn)
+
     def next(self, *kinds):
         n, kind, fn = self.events[self.pos]
         if kind not in kinds:
             raise RuntimeError("chain out of step: the reference did '%s' (event %d), this loop wants %s" % (kind, n, kinds))
         self.pos += 1
-        return kind, read_arrays(fn)
+        return kind, self._arrays(n, fn)
 
     def peek(self):
         return self.events[self.pos][1] if self.pos < len(self.events) else None
@@ -82,7 +92,7 @@ class ChainFixture:
         """(event number, arrays) of the next event of this kind at or after the cursor, without moving the cursor"""
         for n, k, fn in self.events[self.pos:]:
             if k == kind:
-                return n, read_arrays(fn)
+                return n, self._arrays(n, fn)
         return None, None
 
 
