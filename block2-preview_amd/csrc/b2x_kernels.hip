@@ -412,14 +412,30 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
     // them.  Left alone, hipcc hoists all 4*TMF ds_reads to the top of the block (2 VGPRs each), which at
     // TMF = 16 exceeds the 256-VGPR budget of two waves per SIMD and spills inside the loop.
     auto pin_schedule = [&](auto nks) __attribute__((always_inline)) {
-        constexpr int NRD = decltype(nks)::value * TMF, LEAD = NRD < 6 ? NRD : 6;
-        __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0); // DS reads
+        if constexpr (TMF <= 5 && CF == 2) {
+            // Bodies of the register-capped classes (<= 168 / 128 VGPRs): hipcc merges the reads of two neighbouring
+            // fragments into one ds_read2st64_b64, so a k-step is (TMF + 1) / 2 LDS instructions, and under the cap it gave
+            // ALL of them the same four registers — read, wait, four MFMAs, read, wait, ... with the LDS latency exposed
+            // twelve times per chunk.  Pinned instead: two LDS instructions in flight, the next one issued before the
+            // MFMAs of the previous pair (eight registers for A).
+            constexpr int NDS = decltype(nks)::value * ((TMF + 1) / 2), LEADI = NDS < 2 ? NDS : 2;
+            __builtin_amdgcn_sched_group_barrier(0x100, LEADI, 0);
 #pragma unroll
-        for (int i = 0; i < NRD - LEAD; i++) {
-            __builtin_amdgcn_sched_group_barrier(0x008, CF, 0); // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            for (int i = 0; i < NDS - LEADI; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * CF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, LEADI * 2 * CF, 0);
+        } else {
+            constexpr int NRD = decltype(nks)::value * TMF, LEAD = NRD < 6 ? NRD : 6;
+            __builtin_amdgcn_sched_group_barrier(0x100, LEAD, 0); // DS reads
+#pragma unroll
+            for (int i = 0; i < NRD - LEAD; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, CF, 0); // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, LEAD * CF, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, LEAD * CF, 0);
     };
     // The MFMA block: all TMF x CF fragments in ONE basic block for both image layouts (a branch over the
     // layouts would give every accumulator two definitions and hipcc then keeps two copies of the tile).
@@ -429,16 +445,26 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
     //   kmaj   image: (row, k) at (row>>4)*16*KC + k*16 + (row&15)         (conflict-free as it stands)
     // with row = f*16 + c, k = 4s + g.
     // k-steps [S0, S0 + NS) of the chunk
+    // (the lane's element offset of k-step s inside a fragment for the layout of the CURRENT chunk's segment: kept in KS
+    //  registers and rewritten only when the layout changes — both layouts' offsets held side by side and selected per
+    //  chunk cost 2 KS registers and 2 KS VALU instructions per chunk, in bodies that have 4 registers for A fragments)
+    int aoff[KS];
+    auto set_layout = [&](bool kmaj) __attribute__((always_inline)) {
+        const int sw = KC == 16 ? ((c >> 1) & 7) : c;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int o_row = c * KC + 2 * ((2 * s + (g >> 1)) ^ sw) + (g & 1);
+            const int o_k = (4 * s + g) * 16 + c;
+            aoff[s] = kmaj ? o_k : o_row;
+        }
+    };
     auto compute = [&](const double *As, bool kmaj, auto s0c, auto nsc) __attribute__((always_inline)) {
         constexpr int S0 = decltype(s0c)::value, NS = decltype(nsc)::value;
-        const int sw = KC == 16 ? ((c >> 1) & 7) : c;
+        (void)kmaj;
         const double *pb[NS];
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-            const int o_row = c * KC + 2 * ((2 * (S0 + s) + (g >> 1)) ^ sw) + (g & 1);
-            const int o_k = (4 * (S0 + s) + g) * 16 + c;
-            pb[s] = As + (kmaj ? o_k : o_row);
-        }
+        for (int s = 0; s < NS; s++)
+            pb[s] = As + aoff[S0 + s];
 #pragma unroll
         for (int s = 0; s < NS; s++)
 #pragma unroll
@@ -504,6 +530,7 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
         fetch(0, lds);
         commit();
         bool cur_kmaj = s_kmaj;
+        set_layout(cur_kmaj);
         // A chunk with at most KC/2 valid k (the tail of a segment whose K is not a multiple of the chunk depth; a whole
         // segment at tiny K) runs the first half of its k-steps only: the B fragments of the other half are zero.
         bool cur_short = S.K <= KC / 2;
@@ -558,7 +585,10 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
                 break;
             buf ^= 1;
             commit();
-            cur_kmaj = s_kmaj;
+            if (cur_kmaj != s_kmaj) { // (wave-uniform; only at a switch between segments of different A layouts)
+                cur_kmaj = s_kmaj;
+                set_layout(cur_kmaj);
+            }
             cur_short = S.K - nkb <= KC / 2; // (S is the segment of the chunk at nkb by now)
             __syncthreads();
             si = nsi, kb = nkb;
