@@ -157,7 +157,11 @@ def sweep_leg(args):
                        "Teig": tm.get("eigs", 0.0),
                        "Tprt": round(tm.get("noise.record", 0) + tm.get("noise.device", 0), 4),
                        "Tblk": round(tm.get("block", 0) + tm.get("rotate", 0) + tm.get("transform", 0) + tm.get("assign", 0), 4),
-                       "Tsplt": tm.get("split", 0.0)}
+                       "Tsplt": tm.get("split", 0.0),
+                       # inside Teig: moving the previous site's wavefunction to this site (sweep.DMRG._guess, host)
+                       "Tguess": tm.get("guess", 0.0),
+                       "starts": {h: sum(1 for k, v in dm.guess_log.items() if k[0] == isw and v and v[0] == h)
+                                  for h in ("previous", "same", "diagonal")}}
                 rts = ref_times.get(name, {}).get("default", {}).get("sweeps", [])
                 if isw < len(rts):
                     rt = rts[isw]

@@ -154,6 +154,13 @@ class DMRG:
         self.site_key = None
         self.ahead = None                # (event number, new MPS tensor): a split made before the move (split_site)
         self.last_split = None           # {"error": discarded weight, "mmps": kept states} of the last split
+        # the state carried from site to site (block2: MPS::tensors / MPSInfo): the MPS tensors on both sides of the centre,
+        # the site bases, and the wavefunction half of the last split — what the next site's Davidson starts from (_guess)
+        self.use_previous = True         # False: every site starts from the low end of the diagonal (the round-2 behaviour)
+        self.basis, self.mpsL, self.mpsR = {}, {}, {}
+        self.carry, self._at = None, None
+        self.guess_log = {}              # (sweep, site) -> (how the starting vector was made: "previous" / "same" / "diagonal",
+                                         #                   its overlap with the solution)
 
     # ---- steps ------------------------------------------------------------------------------------------------
     def _assign(self, d):
@@ -198,6 +205,7 @@ class DMRG:
         t0 = time.perf_counter()
         right = bool(d["meta"][2])
         pre = "rop" if right else "lop"  # the block-operator side of tensor_product's (lop, rop)
+        self._last_basis = self._site_basis(d, "lop" if right else "rop")
         xl = int(d["x.len"][0])
         lens = [(_info(d, i)["len"] if o >= 0 else 0) for i, o in zip(d[pre + ".info"], d[pre + ".off"])]
         x, tmp = self._repack(blk, d[pre + ".key"], d[pre + ".off"], lens, xl)
@@ -229,6 +237,21 @@ class DMRG:
             x.close()
         self.tm.add("block", t0)
         return out
+
+    def _site_basis(self, d, pre):
+        """StateInfo of the site of a blocking event (block2: MPSInfo::basis[i]): the labels of a site operator without a
+        quantum-number change list every site state once, in block2's order -> ([(n, 2S or 2Sz, pg)], [n_states])"""
+        best = None
+        for i in sorted(set(int(x) for x in d[pre + ".info"])):
+            inf = _info(d, i)
+            if inf["dq"] == 0 and (best is None or len(inf["q"]) > len(best["q"])):
+                best = inf
+        if best is None:
+            return None
+        n, _, tw, pg = _fields(best["q"])
+        if self.sym == "sz":
+            tw = np.where(tw >= 32768, tw - 65536, tw)
+        return [(int(a), int(b), int(c)) for a, b, c in zip(n, tw, pg)], [int(x) for x in best["nket"]]
 
     def _rotate(self, d, enl, mps):
         """rotated block = A^T . enlarged . A per operator sector: symbolic_rotate records the GEMM pairs"""
@@ -359,12 +382,16 @@ class DMRG:
             assert q["n"] == n
             capi.check(capi.lib().b2x_vec_axpy(C.c_double(1.0), C.c_void_p(q["diag"].ptr), C.c_void_p(diag.ptr), C.c_size_t(n), None))
         more = [q["plan"]._h.value for q in parts[1:]]
-        # Initial guess.  block2 starts Davidson from the wavefunction of the previous site; this loop carries no
-        # wavefunction from site to site, so it starts from the low end of the diagonal (the usual Davidson guess) and
-        # checks the answer against the variational bound E0 <= min(diag): a Ritz pair with a tiny residual above that
-        # bound is an excited state the iteration fell into, and the site is solved again from the lowest diagonal entry.
+        # Initial guess.  block2 starts Davidson from the wavefunction of the previous site moved to this one
+        # (MovingEnvironment::propagate_wfn + contract_two_dot); so does this loop (_guess).  Where there is no previous
+        # wavefunction (the first site of a calculation) it starts from the low end of the diagonal, the usual Davidson
+        # guess.  Either way the answer is checked against the variational bound E0 <= min(diag): a Ritz pair with a tiny
+        # residual above that bound is an excited state the iteration fell into, and the site is solved again from the
+        # lowest diagonal entry.
         dg = diag.download()
-        guess = 1.0 / (dg - dg.min() + 0.1) ** 2 + 1e-3 * self.rng.standard_normal(n)
+        guess, how = self._guess(p0["kinfo"]) if self.use_previous else (None, None)
+        if guess is None:
+            guess, how = 1.0 / (dg - dg.min() + 0.1) ** 2 + 1e-3 * self.rng.standard_normal(n), "diagonal"
         ket = capi.DeviceBuffer(n, guess)
         ndav = 0
         for attempt in range(4):
@@ -376,6 +403,7 @@ class DMRG:
             guess[np.argsort(dg)[:attempt + 1]] += 1.0
             ket.upload(guess)
         psi = ket.download()
+        self._guess_how = (how, float(abs(guess @ psi) / max(np.linalg.norm(guess) * np.linalg.norm(psi), 1e-300)))
         self.tm.add("eigs", t0)
         if os.environ.get("B2X_SWEEP_DEBUG"):  # residual of the returned pair, and the diagonal as the kernels built it
             sig = capi.DeviceBuffer(n)
@@ -401,6 +429,150 @@ class DMRG:
 
     def _eigs(self, d, noise_event=None):
         return self._solve([self._eff_ham(d)], noise_event)
+
+    # ---- the wavefunction carried to the next site ----------------------------------------------------------------
+    def _fuse(self, a, b):
+        """labels of the product of two states (S::operator+): SU2 couples |Sa - Sb| .. Sa + Sb, SZ adds"""
+        if self.sym == "sz":
+            return [(a[0] + b[0], a[1] + b[1], a[2] ^ b[2])]
+        return [(a[0] + b[0], t, a[2] ^ b[2]) for t in range(abs(a[1] - b[1]), a[1] + b[1] + 1, 2)]
+
+    def _connection(self, ak, ad, bk, bd):
+        """StateInfo::get_connection_info (src/core/state_info.hpp:283-311): for every fused label the (i, j) pairs of a (x) b
+        that land in it, first index outermost, and where each pair's a_i * b_j states start -> {label: [width, {(i, j): start}]}"""
+        out = {}
+        for i, qa in enumerate(ak):
+            for j, qb in enumerate(bk):
+                for q in self._fuse(qa, qb):
+                    e = out.setdefault(q, [0, {}])
+                    e[1][(i, j)] = e[0]
+                    e[0] += ad[i] * bd[j]
+        return out
+
+    def _recoupling(self, ta, tb, tc, td, te, tf):
+        """the factor of SparseMatrix::swap_to_fused_left / _right (src/core/sparse_matrix.hpp:1838-1843, 1911-1916):
+        racah(a, b, c, d, e, f) sqrt((2e + 1)(2f + 1)), racah = (-1)^(a+b+c+d) {a b e; d c f} (clebsch_gordan.hpp:177-180);
+        1 for SZ"""
+        if self.sym == "sz":
+            return 1.0
+        memo = self.__dict__.setdefault("_racah_memo", {})
+        k = (ta, tb, tc, td, te, tf)
+        v = memo.get(k)
+        if v is None:
+            v = memo[k] = (1 - ((ta + tb + tc + td) & 2)) * self.host.wigner_6j(ta, tb, te, td, tc, tf) * np.sqrt(
+                (te + 1.0) * (tf + 1.0))
+        return v
+
+    def _guess(self, kinfo):
+        """Davidson's starting vector for the site the environments were just moved to (self._at): the wavefunction of the
+        previous site carried over as block2 does.  After the split psi = L . (S V^T) of a forward step the wavefunction
+        half, a matrix [bond] x [fused (site, right bond)], is regrouped to [fused (bond, site)] x [right bond]
+        (MPSInfo::swap_wfn_to_fused_left, src/dmrg/mps.hpp:715-742; SU2: one Racah coefficient per pair of coupling
+        paths) and multiplied with the MPS tensor of the site to its right (MovingEnvironment::contract_two_dot,
+        src/dmrg/moving_environment.hpp:3319-3362, SparseMatrix::contract, sparse_matrix.hpp:1742-1786); the backward
+        step mirrors it.  The bond and site StateInfos are this loop's own (its split, the tensors it rotated with, the
+        site operators' labels); a structure it cannot match returns (None, None) and the caller falls back.
+        -> (vector in kinfo's layout, "previous" | "same") or (None, None)"""
+        t0 = time.perf_counter()
+        try:
+            return self._guess_impl(kinfo)
+        finally:
+            self.tm.add("guess", t0)
+
+    def _guess_impl(self, kinfo):
+        i, forward = self._at
+        c = self.carry
+        if c is None:
+            # the turn-around of a sweep: the same two sites again, in the same bases
+            if (self.psi is not None and self.site_key is not None and self.site_key[1] == i
+                    and len(self.psi[0]) == kinfo["len"] and np.array_equal(self.psi[1]["q"], kinfo["q"])
+                    and np.array_equal(self.psi[1]["nbra"], kinfo["nbra"]) and np.array_equal(self.psi[1]["nket"], kinfo["nket"])):
+                return self.psi[0].copy(), "same"
+            return None, None
+        if c["forward"] != forward or c["site"] != (i - 1 if forward else i + 1):
+            return None, None
+        _, _, ttw, _ = _fields(np.array([kinfo["dq"]], np.uint64))
+        ttw = int(ttw[0])
+        ln, ltw, lpg = self._bond_labels(kinfo, False)
+        rn, rtw, rpg = self._bond_labels(kinfo, True)
+        out = np.zeros(kinfo["len"])
+        blocks = c["blocks"]
+        if forward:
+            # previous sites (i - 1, i): blocks[(a, mr)] = [a] x [fused (m_i, r_{i+1})]; now [fused (a, m_i)] x [r_{i+1}] . R_{i+1}
+            t, m = self.mpsR.get(i + 1), self.basis.get(i)
+            la = self.mpsL.get(i)
+            if t is None or m is None or la is None:
+                return None, None
+            ak, ad = la["keys"], [int(x) for x in la["info"]["nket"]]
+            mk, md = m
+            rk, rd = t["keys"], [int(x) for x in t["info"]["nbra"]]
+            lm, mr = self._connection(ak, ad, mk, md), self._connection(mk, md, rk, rd)
+            rpos = {q: j for j, q in enumerate(rk)}
+            for b in range(len(ln)):
+                ql, qr = (int(ln[b]), int(ltw[b]), int(lpg[b])), (int(rn[b]), int(rtw[b]), int(rpg[b]))
+                nb, nk = int(kinfo["nbra"][b]), int(kinfo["nket"][b])
+                ic = rpos.get(qr)
+                if ic is None or ql not in lm:
+                    continue
+                ti = t["info"]
+                if lm[ql][0] != nb or int(ti["nket"][ic]) != nk:
+                    return None, None
+                w = np.zeros((nb, rd[ic]))
+                for (ia, im), off in lm[ql][1].items():
+                    rows = ad[ia] * md[im]
+                    for qmr in self._fuse(mk[im], rk[ic]):
+                        src = blocks.get((ak[ia], qmr))
+                        if src is None:
+                            continue
+                        if src.shape[1] != mr[qmr][0]:
+                            return None, None
+                        p = mr[qmr][1][(im, ic)]
+                        f = self._recoupling(ak[ia][1], mk[im][1], ttw, rk[ic][1], ql[1], qmr[1])
+                        w[off:off + rows] += f * src[:, p:p + md[im] * rd[ic]].reshape(rows, rd[ic])
+                o = t["base"] + int(ti["ntot"][ic])
+                rblk = t["data"][o:o + rd[ic] * nk].reshape(rd[ic], nk)
+                o = int(kinfo["ntot"][b])
+                out[o:o + nb * nk] = (w @ rblk).reshape(-1)
+        else:
+            # previous sites (i + 1, i + 2): blocks[(lm, a)] = [fused (l_{i+1}, m_{i+1})] x [a]; now L_i . [l_{i+1}] x [fused (m_{i+1}, a)]
+            t, m = self.mpsL.get(i + 1), self.basis.get(i + 1)
+            ra = self.mpsR.get(i + 2)
+            if t is None or m is None or ra is None:
+                return None, None
+            ak, ad = ra["keys"], [int(x) for x in ra["info"]["nbra"]]
+            mk, md = m
+            lk, ld = t["keys"], [int(x) for x in t["info"]["nket"]]
+            lm, mr = self._connection(lk, ld, mk, md), self._connection(mk, md, ak, ad)
+            lpos = {q: j for j, q in enumerate(lk)}
+            for b in range(len(ln)):
+                ql, qr = (int(ln[b]), int(ltw[b]), int(lpg[b])), (int(rn[b]), int(rtw[b]), int(rpg[b]))
+                nb, nk = int(kinfo["nbra"][b]), int(kinfo["nket"][b])
+                ib = lpos.get(ql)
+                if ib is None or qr not in mr:
+                    continue
+                ti = t["info"]
+                if mr[qr][0] != nk or int(ti["nbra"][ib]) != nb:
+                    return None, None
+                w = np.zeros((ld[ib], nk))
+                for (im, ia), off in mr[qr][1].items():
+                    cols = md[im] * ad[ia]
+                    for qlm in self._fuse(lk[ib], mk[im]):
+                        src = blocks.get((qlm, ak[ia]))
+                        if src is None:
+                            continue
+                        if src.shape[0] != lm[qlm][0]:
+                            return None, None
+                        p = lm[qlm][1][(ib, im)]
+                        f = self._recoupling(ak[ia][1], mk[im][1], ttw, lk[ib][1], qr[1], qlm[1])
+                        w[:, off:off + cols] += f * src[p:p + ld[ib] * md[im], :].reshape(ld[ib], cols)
+                o = t["base"] + int(ti["ntot"][ib])
+                lblk = t["data"][o:o + nb * ld[ib]].reshape(nb, ld[ib])
+                o = int(kinfo["ntot"][b])
+                out[o:o + nb * nk] = (lblk @ w).reshape(-1)
+        nrm = np.linalg.norm(out)
+        if not np.isfinite(nrm) or nrm < 1e-8:
+            return None, None
+        return out / nrm, "previous"
 
     def _bond_labels(self, info, right):
         """(n, 2S or 2Sz, pg) of the bond index of every block of a two-site wavefunction: its right label when the
@@ -454,6 +626,16 @@ class DMRG:
         self.ahead = (num, self._split(d, not forward))
         return self.last_split
 
+    def _mps_tensor(self, d, a):
+        """(data, info, offset of block 0, bond labels, bond dimensions) of the MPS tensor a rotation event is made with: a left
+        tensor is (fused rows) x (kept states), a right one (kept states) x (fused columns); block label = bond label"""
+        info = _info(d, d["mps.info"][0])
+        n, _, tw, pg = _fields(info["q"])
+        if self.sym == "sz":
+            tw = np.where(tw >= 32768, tw - 65536, tw)
+        keys = [(int(x), int(y), int(z)) for x, y, z in zip(n, tw, pg)]
+        return {"data": np.asarray(a, np.float64), "info": info, "base": int(d["mps.off"][0]), "keys": keys}
+
     def _take_split(self, d, right):
         num = self.fx.events[self.fx.pos - 1][0]
         if self.ahead is not None and self.ahead[0] == num:
@@ -488,7 +670,7 @@ class DMRG:
                     rho += b.T @ b if right else b @ b.T
             return rho
 
-        kept_of, spectrum = {}, {}
+        kept_of, spectrum, rot = {}, {}, {}
         kept_w, mmps = 0.0, 0
         for s in range(len(ainfo["q"])):
             key = (int(an[s]), int(atw[s]), int(apg[s]))
@@ -498,11 +680,27 @@ class DMRG:
             kept_of[key], spectrum[key] = kept, w[::-1]
             kept_w, mmps = kept_w + float(w[::-1][:kept].sum()), mmps + kept
             u = u[:, ::-1][:, :kept]  # largest weights first
+            rot[key] = u
             blk = u.T if right else u
             o = base + int(ainfo["ntot"][s])
             out[o:o + rows * cols] = blk.reshape(-1)
         trace = sum(float(data @ data) for data, _, _ in srcs)
         self.last_split = {"error": max(0.0, trace - kept_w), "mmps": mmps}
+        if self.use_previous:
+            # the other half of the decomposition — block2's new wavefunction tensor, S.V^T of the forward step (rotation^T . psi)
+            # or U.S of the backward step (psi . rotation^T) — kept per (left label, right label) for the next site's guess
+            psi, kinfo, (bn, btw, bpg) = srcs[0]
+            on, otw, opg = self._bond_labels(kinfo, not right)
+            blocks = {}
+            for i in range(len(bn)):
+                u = rot.get((int(bn[i]), int(btw[i]), int(bpg[i])))
+                if u is None or u.shape[1] == 0:
+                    continue
+                b = psi[kinfo["ntot"][i]:kinfo["ntot"][i] + kinfo["nbra"][i] * kinfo["nket"][i]].reshape(
+                    int(kinfo["nbra"][i]), int(kinfo["nket"][i]))
+                kb, ko = (int(bn[i]), int(btw[i]), int(bpg[i])), (int(on[i]), int(otw[i]), int(opg[i]))
+                blocks[(ko, kb) if right else (kb, ko)] = b @ u if right else u.T @ b
+            self.carry = {"forward": not right, "site": self.site_key[1], "blocks": blocks}
         if self.check_truncation:
             self._check_truncation(right, kept_of, spectrum, rho_of)
         self.tm.add("split", t0)
@@ -563,12 +761,14 @@ class DMRG:
         enl = self._assign(fx.next("rasg")[1])
         while True:
             d = fx.next("rrot")[1]
+            self.mpsR[j] = self._mps_tensor(d, d["arena"])
             self.R[j] = self._rotate_and_transform(d, enl, d["arena"])
             enl.close()
             if j == 2:
                 break
             enl = self._block(fx.next("rblk")[1], self.R[j])
             j -= 1
+            self.basis[j] = self._last_basis
         return sorted(self.R)
 
     def sweep(self, isw, forward):
@@ -599,15 +799,19 @@ class DMRG:
         self.psi = (psi, kinfo)
         self.site_key = (isw, i)
         self.energies[(isw, i)], self.ndav[(isw, i)] = e, ndav
+        self.guess_log[(isw, i)] = getattr(self, "_guess_how", None)
+        self.carry = None  # (set again by the split of this site; none follows at the turn-around of a sweep)
 
     def _move_to(self, i, forward):
         """MovingEnvironment::move_to(i) + the two blockings of the site: the enlarged left / right blocks of site i in HBM"""
         fx, n = self.fx, self.n_sites
+        self._at = (i, forward)
         if forward:
             if i > 0:  # move_to(i): rotate the enlarged left block of the previous site with the new MPS tensor
                 _, d = fx.next("lasg", "lblk")   # (the reference re-contracts it; it is still in HBM here)
                 _, d = fx.next("lrot")
                 a = self._take_split(d, False)
+                self.mpsL[i] = self._mps_tensor(d, a)  # tensor of site i - 1; its column bond is left_dims[i]
                 self.L[i] = self._rotate_and_transform(d, self.EL, a)
             if self.EL is not None:
                 self.EL.close()
@@ -615,17 +819,20 @@ class DMRG:
                 self.EL = self._assign(fx.next("lasg")[1])
             else:
                 self.EL = self._block(fx.next("lblk")[1], self.L[i])
+                self.basis[i] = self._last_basis
             if self.ER is not None:
                 self.ER.close()
             if i == n - 2:
                 self.ER = self._assign(fx.next("rasg")[1])
             else:
                 self.ER = self._block(fx.next("rblk")[1], self.R[i + 2])
+                self.basis[i + 1] = self._last_basis
         else:
             if i < n - 2:  # move_to(i): rotate the enlarged right block of the previous site
                 _, d = fx.next("rasg", "rblk")
                 _, d = fx.next("rrot")
                 a = self._take_split(d, True)
+                self.mpsR[i + 2] = self._mps_tensor(d, a)  # tensor of site i + 2; its row bond is right_dims[i + 2]
                 if i + 2 in self.R:
                     self.R[i + 2].close()
                 self.R[i + 2] = self._rotate_and_transform(d, self.ER, a)
@@ -635,12 +842,14 @@ class DMRG:
                 self.ER = self._assign(fx.next("rasg")[1])
             else:
                 self.ER = self._block(fx.next("rblk")[1], self.R[i + 2])
+                self.basis[i + 1] = self._last_basis
             if self.EL is not None:
                 self.EL.close()
             if i == 0:
                 self.EL = self._assign(fx.next("lasg")[1])
             else:
                 self.EL = self._block(fx.next("lblk")[1], self.L[i])
+                self.basis[i] = self._last_basis
 
 
 class SumMPODMRG:
