@@ -11,7 +11,9 @@
 #include <cstring>
 #include <hip/hip_runtime.h>
 #include <string>
+#include <map>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 using namespace b2x;
@@ -81,11 +83,13 @@ void pool_trim_locked(size_t keep_bytes) {
 // itself holds are given back first — the buffer pool, then the parked plans of the compiled-plan cache (their work lists) —
 // and the allocation is retried.  (b2x_trim does the same on request, for other allocators of the process.)
 static size_t reclaim_cached_plans(); // defined behind the plan cache
+static size_t vec_cache_flush();      // defined with b2x_device_alloc
 static hipError_t dev_malloc(void **out, size_t bytes) {
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipSuccess)
         return e;
     (void)hipGetLastError();
+    vec_cache_flush();
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         pool_trim_locked(0);
@@ -487,17 +491,82 @@ int b2x_device_sync(void) {
     HIPCHK(hipDeviceSynchronize());
     return B2X_OK;
 }
+// b2x_device_alloc / b2x_device_free keep freed vectors for the next request of the same size class.  A sweep allocates and
+// frees the same handful of sizes at every site (enlarged and rotated blocks, the operator arena, psi-sized vectors), and a
+// hipMalloc of tens of MB costs about a millisecond, a hipFree a device-wide wait: of the 35 ms an H10 M=500 site took on the
+// host, 8 were these calls (tools/sweep_profile.py).  Size classes are 1/8 octave wide (<= 12.5 % slack behind a vector); a
+// buffer is parked only after the device is idle (what hipFree waits for as well), so a parked buffer has no reader left.
+// B2X_VEC_CACHE_MB caps the parked bytes (default 1/16 of the card, 0 = off); the oldest parked buffers go first; an
+// allocation that fails anywhere in the library flushes the cache before it gives up (dev_malloc), b2x_trim flushes it too.
+namespace {
+struct ParkedVec {
+    void *p;
+    uint64_t seq;
+};
+std::mutex g_vc_mu;
+std::multimap<size_t, ParkedVec> g_vc_free;      // parked buffers by capacity
+std::unordered_map<void *, size_t> g_vc_live;   // capacity of every vector handed out
+size_t g_vc_bytes = 0;
+uint64_t g_vc_seq = 0;
+size_t vec_cache_cap() {
+    static const size_t cap = []() -> size_t {
+        if (const char *e = getenv("B2X_VEC_CACHE_MB"))
+            return (size_t)atoll(e) << 20;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess)
+            (void)hipGetLastError(), tot = (size_t)64 << 30;
+        return tot / 16;
+    }();
+    return cap;
+}
+size_t vec_class(size_t bytes) {
+    if (bytes <= 4096)
+        return 4096;
+    const int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = (size_t)1 << (lg - 3);
+    return (bytes + step - 1) & ~(step - 1);
+}
+} // namespace
+static size_t vec_cache_flush() {
+    std::vector<void *> out;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_vc_mu);
+        for (auto &kv : g_vc_free)
+            out.push_back(kv.second.p), bytes += kv.first;
+        g_vc_free.clear();
+        g_vc_bytes = 0;
+    }
+    for (void *p : out)
+        (void)hipFree(p);
+    return bytes;
+}
 int b2x_device_alloc(void **dptr, size_t bytes) {
     if (!dptr)
         return fail(B2X_ERR_INVALID, "b2x_device_alloc: null argument");
-    if (dev_malloc(dptr, bytes ? bytes : 8) != hipSuccess)
+    const size_t cap = vec_class(bytes ? bytes : 8);
+    {
+        std::lock_guard<std::mutex> lk(g_vc_mu);
+        auto it = g_vc_free.find(cap);
+        if (it != g_vc_free.end()) {
+            *dptr = it->second.p;
+            g_vc_free.erase(it);
+            g_vc_bytes -= cap;
+            g_vc_live[*dptr] = cap;
+            return B2X_OK;
+        }
+    }
+    if (dev_malloc(dptr, cap) != hipSuccess)
         return fail(B2X_ERR_NOMEM, "b2x_device_alloc: out of device memory");
+    std::lock_guard<std::mutex> lk(g_vc_mu);
+    g_vc_live[*dptr] = cap;
     return B2X_OK;
 }
 int b2x_trim(uint64_t *bytes_released) {
     size_t f0 = 0, f1 = 0, tot = 0;
     (void)hipMemGetInfo(&f0, &tot);
     reclaim_cached_plans();
+    vec_cache_flush();
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
         pool_trim_locked(0);
@@ -509,7 +578,37 @@ int b2x_trim(uint64_t *bytes_released) {
     return B2X_OK;
 }
 int b2x_device_free(void *dptr) {
-    HIPCHK(hipFree(dptr));
+    if (!dptr)
+        return B2X_OK;
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_vc_mu);
+        auto it = g_vc_live.find(dptr);
+        if (it != g_vc_live.end())
+            cap = it->second, g_vc_live.erase(it);
+    }
+    if (cap == 0 || vec_cache_cap() == 0 || cap > vec_cache_cap() / 4) { // not from b2x_device_alloc, or too big to park
+        HIPCHK(hipFree(dptr));
+        return B2X_OK;
+    }
+    HIPCHK(hipDeviceSynchronize()); // (hipFree's own guarantee: nothing on the device still reads the vector)
+    std::vector<void *> evict;
+    {
+        std::lock_guard<std::mutex> lk(g_vc_mu);
+        g_vc_free.emplace(cap, ParkedVec{dptr, g_vc_seq++});
+        g_vc_bytes += cap;
+        while (g_vc_bytes > vec_cache_cap()) { // oldest first
+            auto old = g_vc_free.begin();
+            for (auto it = g_vc_free.begin(); it != g_vc_free.end(); ++it)
+                if (it->second.seq < old->second.seq)
+                    old = it;
+            evict.push_back(old->second.p);
+            g_vc_bytes -= old->first;
+            g_vc_free.erase(old);
+        }
+    }
+    for (void *p : evict)
+        (void)hipFree(p);
     return B2X_OK;
 }
 int b2x_memcpy_h2d(void *dst, const void *src, size_t bytes) {

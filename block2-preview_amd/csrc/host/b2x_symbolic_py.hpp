@@ -291,7 +291,8 @@ template <typename S> py::tuple sym_rotate(const py::dict &d, bool execute) {
     const uint64_t *meta = SymEH<S>::template arr<uint64_t>(d, "meta");
     const bool right = meta[2] != 0;
     py::array_t<double> v((py::ssize_t)meta[6]);
-    std::fill(v.mutable_data(), v.mutable_data() + v.size(), 0.0);
+    if (execute) // (recording needs the ADDRESSES of the rotated blocks only: the pages of v are not touched, and v is returned uninitialised)
+        std::fill(v.mutable_data(), v.mutable_data() + v.size(), 0.0);
     size_t n;
     const int64_t *ai = SymEH<S>::template arr<int64_t>(d, "a.info", &n), *ci = SymEH<S>::template arr<int64_t>(d, "c.info"),
                   *ao = SymEH<S>::template arr<int64_t>(d, "a.off"), *co = SymEH<S>::template arr<int64_t>(d, "c.off");
@@ -349,7 +350,8 @@ template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
     if (!meta[3])
         throw std::runtime_error("fixture holds expression forms this mirror does not cover (operator sums without an intermediate)");
     py::array_t<double> v((py::ssize_t)meta[7]);
-    std::fill(v.mutable_data(), v.mutable_data() + v.size(), 0.0);
+    if (execute) // (as in sym_rotate: a recording walk never reads or writes v — an enlarged block is tens of MB that would be faulted in)
+        std::fill(v.mutable_data(), v.mutable_data() + v.size(), 0.0);
     // lop / rop as TensorFunctions::tensor_product receives them: left blocking (block, site), right blocking (site, block)
     auto load = [&](const std::string &pre, double *base) {
         OperatorTensor<S> t;
@@ -493,7 +495,8 @@ template <typename S> py::array sym_transform(const py::dict &d) {
     typedef SparseMatrixInfo<S> Info;
     std::map<int, std::shared_ptr<Info>> cache;
     const uint64_t *meta = SymEH<S>::template arr<uint64_t>(d, "meta");
-    std::vector<double> t((size_t)meta[3] + 1, 0.0); // address space of the block's vector (values are never read)
+    std::unique_ptr<double[]> t_mem(new double[(size_t)meta[3] + 1]); // address space of the block's vector: never read, never
+    double *const t_base = t_mem.get();                               // written, so its pages are never touched
     size_t n;
     const int64_t *iid = SymEH<S>::template arr<int64_t>(d, "t.info", &n), *off = SymEH<S>::template arr<int64_t>(d, "t.off");
     const double *fac = SymEH<S>::template arr<double>(d, "t.factor");
@@ -501,7 +504,7 @@ template <typename S> py::array sym_transform(const py::dict &d) {
     for (size_t i = 0; i < n; i++) {
         auto m = std::make_shared<SparseMatrix<S>>();
         m->info = SymEH<S>::info(d, (int)iid[i], cache);
-        m->factor = fac[i], m->data = off[i] < 0 ? nullptr : t.data() + off[i];
+        m->factor = fac[i], m->data = off[i] < 0 ? nullptr : t_base + off[i];
         m->total_memory = off[i] < 0 ? 0 : m->info->get_total_memory();
         ops.push_back(m);
     }
@@ -523,9 +526,9 @@ template <typename S> py::array sym_transform(const py::dict &d) {
         }
     std::vector<b2x_outer_term> terms = seq->outer_terms;
     for (size_t i = 0; i < terms.size(); i++) {
-        terms[i].a_src = 1, terms[i].a_off = (uint64_t)(seq->oa_ptr[i] - t.data());
+        terms[i].a_src = 1, terms[i].a_off = (uint64_t)(seq->oa_ptr[i] - t_base);
         terms[i].b_src = 2, terms[i].b_off = 0;
-        terms[i].c_off = (uint64_t)(seq->oc_ptr[i] - t.data());
+        terms[i].c_off = (uint64_t)(seq->oc_ptr[i] - t_base);
     }
     py::array_t<uint8_t> pa(terms.size() * sizeof(b2x_outer_term));
     std::memcpy(pa.mutable_data(), terms.data(), terms.size() * sizeof(b2x_outer_term));

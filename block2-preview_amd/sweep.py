@@ -96,6 +96,43 @@ class ChainFixture:
         return None, None
 
 
+def host_cores():
+    """cores this process may actually use: the affinity mask, cut by the cgroup CPU quota (a container on a 256-thread host
+    with a 16-core quota sees 256 CPUs)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+_blas_limited = False
+
+
+def limit_host_blas():
+    """The host steps of the loop (the density-matrix eigenproblems of a split, the small products of the carried
+    wavefunction) run on numpy's BLAS, whose pool is sized from the CPUs it SEES: on the GPU box that is 64 threads inside a
+    16-core quota, and the sector-sized eigh calls of a split ran 6-8x slower than on one thread, with 10x jitter
+    (tools/blas_threads_probe.py; profiles/r03_host_blas_threads.txt).  Once per process the pool is cut to
+    min(cores available, 8); B2X_HOST_BLAS_THREADS overrides (0 = leave the pool alone)."""
+    global _blas_limited
+    if _blas_limited:
+        return
+    _blas_limited = True
+    want = os.environ.get("B2X_HOST_BLAS_THREADS")
+    n = int(want) if want is not None else min(host_cores(), 8)
+    if n <= 0:
+        return
+    try:
+        from threadpoolctl import threadpool_limits
+    except ImportError:
+        return
+    threadpool_limits(limits=n, user_api="blas")
+
+
 class OpTensor:
     """operator blocks of one (enlarged or rotated) block in HBM: one device vector + {operator key: (offset, length)}"""
 
@@ -140,6 +177,7 @@ class DMRG:
     def __init__(self, fixture, sym, conv_thrd=1e-13, seed=1234):
         from . import b2x_host
 
+        limit_host_blas()
         self.fx, self.sym, self.host = fixture, sym, b2x_host
         self.conv_thrd, self.rng = conv_thrd, np.random.default_rng(seed)
         self.L, self.R = {}, {}          # rotated blocks by the site their enlarged successor starts from

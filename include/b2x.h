@@ -115,7 +115,7 @@ const char *b2x_version(void);
 int b2x_device_count(int *n);
 int b2x_device_init(int ordinal);                 /* hipSetDevice; fails if no gfx950 device */
 int b2x_device_sync(void);
-int b2x_device_alloc(void **dptr, size_t bytes);  /* hipMalloc of exactly `bytes` */
+int b2x_device_alloc(void **dptr, size_t bytes);  /* device vector of at least `bytes` (size classes of 1/8 octave; freed vectors are kept for the next request of the class: B2X_VEC_CACHE_MB, b2x_trim) */
 int b2x_device_free(void *dptr);
 int b2x_memcpy_h2d(void *dst, const void *src, size_t bytes);
 int b2x_memcpy_d2h(void *dst, const void *src, size_t bytes);
