@@ -147,6 +147,50 @@ def test_sum_mpo_four_ranks_energy(gpu):
     assert worst < 1e-7 and abs(e1[-1] - (-107.654122447525)) < 1e-7
 
 
+@pytest.mark.parametrize("chain,sym", [(("chain_n2su2", "n2c"), "su2"), (("chain_h10sz", "h10c"), "sz")])
+def test_davidson_starts_from_the_previous_site(gpu, chain, sym):
+    """MovingEnvironment::propagate_wfn + contract_two_dot (moving_environment.hpp:4458-4486, 3319-3362): the wavefunction half
+    of every split, regrouped to the next site's fused index (SU2: Racah recoupling, sparse_matrix.hpp:1789-1859 / 1861-1927)
+    and multiplied with the neighbouring MPS tensor, is Davidson's starting vector.  In the converged sweep 1 that vector IS
+    the solution (overlap 1 to 1e-9, forward-made tensors and backward regrouping, SU2 and SZ), so a site costs one to a few
+    H.psi; from the diagonal start of earlier rounds the same energies take several times as many."""
+    from block2_preview_amd.sweep import DMRG, ChainFixture
+
+    runs = {}
+    for use in (True, False):
+        fx = ChainFixture(os.path.join(GOLDEN, *chain))
+        dm = DMRG(fx, sym)
+        dm.use_previous = use
+        dm.init_environments()
+        dm.sweep(0, True), dm.sweep(1, False)
+        runs[use] = dm
+    a, b = runs[True], runs[False]
+    n = a.n_sites
+    assert a.guess_log[(0, 0)][0] == "diagonal" and a.guess_log[(1, n - 2)][0] == "same"
+    assert all(a.guess_log[k][0] == "previous" for k in a.guess_log if k not in ((0, 0), (1, n - 2)))
+    assert all(v[0] == "diagonal" for v in b.guess_log.values())
+    sw1 = [k for k in a.guess_log if k[0] == 1]
+    print({k: (round(a.guess_log[k][1], 10), a.ndav[k], b.ndav[k]) for k in sorted(a.guess_log)})
+    assert min(a.guess_log[k][1] for k in sw1) > 1 - 1e-8
+    assert max(a.ndav[k] for k in sw1) <= 8 and sum(a.ndav[k] for k in sw1) * 3 < sum(b.ndav[k] for k in sw1)
+    assert max(abs(a.energies[k] - b.energies[k]) for k in a.energies if k != (0, 0)) < 1e-9
+    assert "guess" in a.tm and a.tm["guess"] < a.tm["eigs"]
+
+
+def test_sum_mpo_sweep_carries_the_wavefunction(gpu):
+    """the 2-rank sum-MPO run: rank 0's carried wavefunction starts every site's Davidson over the summed plans"""
+    from block2_preview_amd.sweep import ChainFixture, SumMPODMRG
+
+    fxs = [ChainFixture(os.path.join(GOLDEN, "chain_n2su2_ij", "n2p.r%dof2" % r)) for r in range(2)]
+    dm = SumMPODMRG(fxs, "su2")
+    dm.init_environments()
+    dm.sweep(0, True), dm.sweep(1, False)
+    log = dm.ranks[0].guess_log
+    assert sum(1 for v in log.values() if v[0] == "previous") == 16
+    assert min(v[1] for k, v in log.items() if k[0] == 1) > 1 - 1e-8
+    assert max(abs(dm.energies[k] - e) for k, e in fxs[0].ref_energy.items()) < 1e-7
+
+
 def _truncation_evidence(dm, fx):
     """what the truncation log of a replayed chain must show for the replay to count as the reference's calculation:
     (i) this loop's OWN choice of kept states (all eigenvalues of all sectors sorted, the largest k kept) gives the reference's
@@ -211,8 +255,9 @@ def test_cr2_svp_m250_energy_gate(gpu):
     state is an eigenvector of the numerical null space of the density matrix) and Davidson converges to 1e-18 on both sides.
     On this schedule the reference reproduces itself to 4e-11 across thread counts (with cutoff = 1e-14 its own runs are 5e-5
     apart: profiles/r03_reference_reproducibility_cr2_m250.txt), and this loop reproduces the reference: every site energy
-    to 1e-7 (2.3e-9 measured), the final energy -2086.3819578583 to 1e-7 (2e-10 measured), the reference's kept states at every
-    one of the 120 bonds, its discarded weights and its whole spectra."""
+    to 1e-9 (5e-11 measured now that Davidson starts from the previous site's wavefunction as the reference's does; 2.3e-9
+    from the diagonal start of earlier rounds), the final energy -2086.3819578583 to 1e-9, the reference's kept states at
+    every one of the 120 bonds, its discarded weights and its whole spectra."""
     fx, dm, es = _noisy(gpu, os.path.join("chain_cr2_m250_cut9", "cr2g"), "su2", 3, 82, conv_thrd=1e-18)
     d = {k: abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items()}
     bonds, same = _truncation_evidence(dm, fx)
@@ -220,23 +265,26 @@ def test_cr2_svp_m250_energy_gate(gpu):
     print("Cr2 M=250 gate: worst |dE| = %.2e over %d sites, final %.10f (reference %.10f), kept states = the fixture's at %d of %d "
           "bonds, spectra to %.1e" % (max(d.values()), len(d), min(es), fx.final_energy, same, bonds, spec))
     assert len(fx.ref_energy) == 123 and dm.n_sites == 42
-    assert max(d.values()) < 1e-7                      # the gate is 1e-6
-    assert abs(min(es) - fx.final_energy) < 1e-7 and abs(fx.final_energy - (-2086.3819578583)) < 1e-9
+    assert max(d.values()) < 1e-9                      # the gate is 1e-6
+    assert abs(min(es) - fx.final_energy) < 1e-9 and abs(fx.final_energy - (-2086.3819578583)) < 1e-9
     assert bonds == 120 and same == 120 and spec < 1e-6
+    starts = [v[0] for v in dm.guess_log.values()]
+    assert starts.count("diagonal") == 1 and starts.count("same") == 2 and starts.count("previous") == 120
 
 
 def test_cr2_svp_m500_energy_gate(gpu):
     """the same gate at M=500 ("GPU path vs true reference at M=250 and M=500"): Cr2/SVP SU2 M=500, noises 1e-5, 0
     (one noisy and one noise-free sweep: 82 sites, 582 events, tests/golden/chain_cr2_m500_cut9/cr2h.zip), cutoff 1e-9, Davidson
-    1e-18.  Every site energy to 1e-7 (1.1e-8 measured), the final energy -2086.2887243370 to 1e-7 (1.4e-9 measured), the
-    reference's kept states at every bond.  (The reference needs 160 + 22 s for the two sweeps on 8 threads, this loop 12 s.)"""
+    1e-18.  Every site energy to 1e-9 (1.8e-11 measured; 1.1e-8 from the diagonal start of earlier rounds), the final energy
+    -2086.2887243370 to 1e-9, the reference's kept states at every bond.  (The reference needs 160 + 22 s for the two sweeps
+    on 8 threads, this loop 4.4 + 1.8 s.)"""
     fx, dm, es = _noisy(gpu, os.path.join("chain_cr2_m500_cut9", "cr2h"), "su2", 2, 41, conv_thrd=1e-18)
     d = {k: abs(dm.energies[k] - ref) for k, ref in fx.ref_energy.items()}
     bonds, same = _truncation_evidence(dm, fx)
     print("Cr2 M=500 gate: worst |dE| = %.2e over %d sites, final %.10f (reference %.10f), kept states = the fixture's at %d of %d bonds"
           % (max(d.values()), len(d), min(es), fx.final_energy, same, bonds))
     assert len(fx.ref_energy) == 82 and dm.n_sites == 42
-    assert max(d.values()) < 1e-7 and abs(min(es) - fx.final_energy) < 1e-7
+    assert max(d.values()) < 1e-9 and abs(min(es) - fx.final_energy) < 1e-9
     assert bonds == 80 and same == 80
 
 
