@@ -122,6 +122,9 @@ def sweep_leg(args):
     # container, quiet machine, no event dumping; "default" = block2's default contraction settings)
     rt_file = os.path.join(GOLD, "ref_sweep_times.json")
     ref_times = json.load(open(rt_file)) if os.path.exists(rt_file) else {}
+    # ... and its Davidson iteration counts per sweep (tests/golden/make_ref_ndav.sh: "Ndav =" of block2's own site lines)
+    nd_file = os.path.join(GOLD, "ref_sweep_ndav.json")
+    ref_ndav = json.load(open(nd_file)) if os.path.exists(nd_file) else {}
     for name in names:
         if name not in SWEEP_CHAINS:
             raise SystemExit("unknown chain %r (have: %s)" % (name, ", ".join(sorted(SWEEP_CHAINS))))
@@ -168,6 +171,9 @@ def sweep_leg(args):
                     row["reference_cpu"] = {"wall_s": rt[0], "Teff": rt[1], "Teig": rt[2], "Tprt": rt[3], "Tblk": rt[4],
                                             "Tsplt": rt[7], "threads": 8, "settings": "block2 defaults"}
                     row["speedup_vs_reference_cpu"] = round(rt[0] / wall, 3)
+                    nd = ref_ndav.get(name, {}).get("per_sweep", [])
+                    if isw < len(nd):
+                        row["reference_cpu"]["n_hpsi"] = nd[isw]
                 sweeps.append(row)
             assert fx.pos == len(fx.events), "the chain was not replayed to its end"
             key = name if rep == 0 else name + "_plans_cached"

@@ -193,16 +193,16 @@ class MovingEnvironment:
         """H_eff of the current centre (moving_environment.hpp:2062-2201): plan + diagonal on the device"""
         if fuse_type != FuseTypes.FuseLR:
             raise NotImplementedError("only the two-site effective Hamiltonian (FuseTypes.FuseLR) is on this path")
-        parts, d0, dn = [], None, None
+        parts, d0, dn = [], None, []
         for eng in self._engs:
             d = eng._eham_event(self._isweep, self.center)
-            if eng.fx.peek() == "enoise":
-                dn = eng.fx.next("enoise")[1]
+            if eng.fx.peek() == "enoise":  # (sum-MPO: one perturbative-noise step per rank, summed on the root)
+                dn.append(eng.fx.next("enoise")[1])
             parts.append(eng._eff_ham(d))
             d0 = d0 if d0 is not None else d
         self.mpo.const_e = parts[0]["const_e"]
         self._last_macs = sum(int(q["plan"].stats["macs"]) for q in parts)
-        return EffectiveHamiltonian(self, parts, d0, dn)
+        return EffectiveHamiltonian(self, parts, d0, (dn if len(dn) > 1 else dn[0]) if dn else None)
 
 
 class DMRG:
@@ -246,6 +246,7 @@ class DMRG:
         self.teig += time.perf_counter() - t0
         for g in me._engs:
             g._finish_site(self.isweep, i, e, ndav, h_eff._solved[2], h_eff._solved[3])
+            g.pket = eng.pket  # (the perturbed wavefunctions summed over the ranks: every rank splits with the same density matrix)
         h_eff.deallocate()
         t0 = time.perf_counter()
         sp = [g.split_site(forward) for g in me._engs][0]

@@ -457,9 +457,21 @@ class DMRG:
         self.const_e = const_e
         self.pket = None
         if noise_event is not None:
-            if len(parts) != 1:
-                raise NotImplementedError("perturbative noise of a sum-MPO site (the reduce of the perturbed kets to the root)")
-            self.pket = self._perturb(noise_event, parts[0], ket)
+            # sum-MPO: every rank perturbs psi with ITS operators into the same layout (the perturbed labels are all-reduced
+            # before the infos are made, effective_hamiltonian.hpp:303-309) and the results are summed on the root
+            # (comm->reduce_sum, :399-400, 416-417); here the ranks' lists run one after another and are added
+            events = noise_event if isinstance(noise_event, (list, tuple)) else [noise_event]
+            if len(events) != len(parts):
+                raise RuntimeError("%d noise events for %d parts of the Hamiltonian" % (len(events), len(parts)))
+            for ev, q in zip(events, parts):
+                pk = self._perturb(ev, q, ket)
+                if self.pket is None:
+                    self.pket = pk
+                else:
+                    if pk["offs"] != self.pket["offs"] or len(pk["data"]) != len(self.pket["data"]):
+                        raise RuntimeError("the ranks' perturbed wavefunctions differ in layout")
+                    self.pket["data"] += pk["data"]
+                    self.pket["n_gemms"] += pk["n_gemms"]
         for q in parts:
             q["plan"].close(), q["arena"].close(), q["arena_t"].close(), q["diag"].close()
         ket.close()
@@ -915,13 +927,17 @@ class SumMPODMRG:
         sites = range(0, n - 1) if forward else range(n - 2, -1, -1)
         out = []
         for i in sites:
-            parts = []
+            parts, noise = [], []
             for r in self.ranks:
                 r._move_to(i, forward)
-                parts.append(r._eff_ham(r._eham_event(isw, i)))
-            e, ndav, psi, kinfo, _ = self.ranks[0]._solve(parts)
+                d = r._eham_event(isw, i)
+                if r.fx.peek() == "enoise":  # a noisy sweep: every rank recorded its own perturbative-noise step
+                    noise.append(r.fx.next("enoise")[1])
+                parts.append(r._eff_ham(d))
+            e, ndav, psi, kinfo, _ = self.ranks[0]._solve(parts, noise or None)
             for r in self.ranks:
                 r._finish_site(isw, i, e, ndav, psi, kinfo)
+                r.pket = self.ranks[0].pket  # (the root's sum; every rank splits with the same density matrix)
             self.energies[(isw, i)] = e
             out.append(e)
         return out

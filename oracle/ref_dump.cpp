@@ -240,8 +240,13 @@ template <typename S> struct CapTF : TensorFunctions<S, double> {
         const vector<vector<shared_ptr<typename SparseMatrixInfo<S>::ConnectionInfo>>> &cinfos, const vector<S> &vdqs,
         const shared_ptr<SparseMatrixGroup<S, FL>> &vmats, int &vidx, int tvidx, bool do_reduce) const override {
         a_psubsl = psubsl, a_vdqs = vdqs, a_vmats = vmats, a_trace_right = trace_right, a_vidx = vidx, a_tvidx = tvidx;
-        TensorFunctions<S, FL>::tensor_product_partial_multiply(expr, xexpr, lopt, ropt, trace_right, cmat, psubsl, cinfos,
-                                                                vdqs, vmats, vidx, tvidx, do_reduce);
+        // a parallel MPO hands over its LOCAL expression wrapped in an OpExprRef (ParallelTensorFunctions unwraps it the same
+        // way, src/core/parallel_tensor_functions.hpp:173-185)
+        auto unwrap = [](const shared_ptr<OpExpr<S>> &e) -> shared_ptr<OpExpr<S>> {
+            return e != nullptr && e->get_type() == OpTypes::ExprRef ? dynamic_pointer_cast<OpExprRef<S>>(e)->op : e;
+        };
+        TensorFunctions<S, FL>::tensor_product_partial_multiply(unwrap(expr), unwrap(xexpr), lopt, ropt, trace_right, cmat, psubsl,
+                                                                cinfos, vdqs, vmats, vidx, tvidx, false);
         auto b0 = this->opf->seq->batch[0], b1 = this->opf->seq->batch[1];
         assert(b0->c.size() == 0 && b1->acidxs.size() == 0);
         size_t n = b1->c.size();
@@ -1103,8 +1108,10 @@ template <typename S> struct Dumper : CallbackKernel {
         auto old_tf = h->tf;
         h->tf = cap;
         const bool forward = (isw % 2 == 0) == start_forward;
+        // (under MPI every rank is here at the same site: the rule makes the perturbed labels the union over the ranks, as in
+        // the real step, so that all ranks record the same layout of the perturbed wavefunctions)
         auto pket = h->perturbative_noise(forward, site, site + 1, FuseTypes::FuseLR, dmrg->me->ket->info,
-                                          dmrg->noise_type, nullptr);
+                                          dmrg->noise_type, dmrg->me->para_rule);
         h->tf = old_tf;
         size_t n = cap->recs.size();
         const double *ket0 = h->ket->data, *ket1 = ket0 + h->ket->total_memory;

@@ -74,6 +74,11 @@ mkdir -p chain_n2su2_ij
 # ... and a 4-rank run
 mkdir -p chain_n2su2_ij4
 /opt/conda/bin/mpirun -n 4 ../../oracle/_ref/ref_dump_mpi $D/N2.STO3G.FCIDUMP su2 200 2 ./chain_n2su2_ij4/n2p para=ij chain=1 nocache=1 nthreads=1 noise=0,0 tol=1e-12 iprint=0
+# ... and with the noisy schedule (every rank records its own perturbative-noise step; the perturbed labels are the union over
+# the ranks); kept as one archive per rank
+mkdir -p chain_n2su2_ij_noisy
+/opt/conda/bin/mpirun -n 2 ../../oracle/_ref/ref_dump_mpi $D/N2.STO3G.FCIDUMP su2 200 3 ./chain_n2su2_ij_noisy/n2pn para=ij chain=2 nocache=1 nthreads=2 noise=1e-5,1e-5,0 tol=1e-12 dav_thrd=1e-13 iprint=0
+(cd chain_n2su2_ij_noisy && for r in 0 1; do zip -q -9 n2pn.r${r}of2.zip n2pn.r${r}of2.* && rm -f n2pn.r${r}of2.ev* n2pn.r${r}of2.log; done)
 # Cr2/SVP at M=30, two sweeps: 539 events, 51 MB raw -> kept as chain_cr2/cr2c.zip (sweep.ChainFixture unpacks it)
 # (round 3: spectra=1 logs the full density-matrix spectrum the reference truncated at every bond, dav_thrd the Davidson
 #  threshold of every sweep; SWEEP_TIME lines = the reference's own per-sweep timers)

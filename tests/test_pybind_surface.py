@@ -227,3 +227,14 @@ def test_noisy_schedule_and_sum_mpo_through_block2_names(gpu):
     ep = px.solve(2, True, 1e-12)
     pref = ranks[0].fixture.ref_energy
     assert max(abs(pme._eng.energies[k] - pref[k]) for k in pref) < 1e-7 and abs(ep - (-107.654122447525)) < 1e-7
+    # ... and the ParallelMPO run WITH the noisy schedule (every rank's perturbed wavefunctions summed before the split)
+    nranks = [b.su2.MPO(os.path.join(GOLDEN, "chain_n2su2_ij_noisy", "n2pn.r%dof2" % r), "su2") for r in range(2)]
+    nmpo, nmps = b.su2.ParallelMPO(nranks, rule), b.su2.MPS()
+    nme = b.su2.MovingEnvironment(nmpo, nmps, nmps, "DMRG")
+    nme.init_environments()
+    nx = b.su2.DMRG(nme, [200], [1e-5, 1e-5, 0.0])
+    nx.noise_type, nx.iprint, nx.davidson_conv_thrds = b.NoiseTypes.ReducedPerturbative, 0, [1e-13] * 3
+    en = nx.solve(3, True, 1e-12)
+    nref = nranks[0].fixture.ref_energy
+    assert len(nref) == 27
+    assert max(abs(nme._eng.energies[k] - nref[k]) for k in nref) < 1e-7 and abs(en - (-107.654122447525)) < 1e-7

@@ -191,6 +191,29 @@ def test_sum_mpo_sweep_carries_the_wavefunction(gpu):
     assert max(abs(dm.energies[k] - e) for k, e in fxs[0].ref_energy.items()) < 1e-7
 
 
+def test_sum_mpo_noisy_schedule_two_ranks(gpu):
+    """the 2-rank ParallelRuleSimple run of the reference WITH perturbative noise (noises 1e-5, 1e-5, 0; tests/golden/
+    chain_n2su2_ij_noisy: 18 noise steps per rank): every rank perturbs psi with its own operators over its own arena, the
+    perturbed wavefunctions (same layout on every rank: the labels are all-reduced, effective_hamiltonian.hpp:303-309) are
+    summed as comm->reduce_sum does on the root (:399-400), every rank splits with the same perturbed density matrix.  All 27
+    site energies of the reference and the in-tree answer."""
+    from block2_preview_amd.sweep import ChainFixture, SumMPODMRG
+
+    fxs = [ChainFixture(os.path.join(GOLDEN, "chain_n2su2_ij_noisy", "n2pn.r%dof2" % r)) for r in range(2)]
+    assert all(sum(1 for _, k, _ in fx.events if k == "enoise") == 18 for fx in fxs)
+    assert len(fxs[0].ref_energy) == 27 and fxs[0].ref_energy == fxs[1].ref_energy
+    dm = SumMPODMRG(fxs, "su2")
+    dm.init_environments()
+    es = dm.sweep(0, True) + dm.sweep(1, False) + dm.sweep(2, True)
+    assert all(fx.pos == len(fx.events) for fx in fxs)
+    worst = max(abs(dm.energies[k] - e) for k, e in fxs[0].ref_energy.items())
+    print("sum-MPO noisy: worst |dE| = %.2e, final %.12f" % (worst, es[-1]))
+    assert worst < 1e-7 and abs(es[-1] - (-107.654122447525)) < 1e-7
+    # the noise changed the states kept: a rank that splits WITHOUT the other rank's perturbed wavefunctions would leave the chain
+    one = fxs[0].ref_energy[(0, 3)]
+    assert abs(dm.energies[(0, 3)] - one) < 1e-9
+
+
 def _truncation_evidence(dm, fx):
     """what the truncation log of a replayed chain must show for the replay to count as the reference's calculation:
     (i) this loop's OWN choice of kept states (all eigenvalues of all sectors sorted, the largest k kept) gives the reference's
