@@ -21,18 +21,18 @@ run cr2_m30      $D/CR2.SVP.FCIDUMP su2 30 2 $T/cr2s noise=0,0 tol=1e-12 dav_thr
 python3 - <<'PY'
 import glob, json, os, re
 T = "/tmp/b2x_ref_ndav"
-out = {"_note": "block2 reference (oracle/_ref/ref_dump, iprint=2): Davidson iterations per sweep (sum of 'Ndav =' over the sites), "
+out = {"_note": "block2 reference (oracle/_ref/ref_dump, iprint=2): Davidson iterations ('Ndav =' of every site line, in visiting order) and their sum per sweep, "
                 "same schedule as the chain of the same name (tests/golden/make_ref_ndav.sh)"}
 for fn in sorted(glob.glob(T + "/*.out")):
     name = os.path.basename(fn)[:-4]
-    per, cur = [], None
+    sites = []  # per sweep, in the order the sweep visits its sites
     for l in open(fn, errors="replace"):
         if re.match(r"\s*Sweep =", l):
-            per.append(0)
+            sites.append([])
         m = re.search(r"Ndav =\s*(\d+)", l)
-        if m and per:
-            per[-1] += int(m.group(1))
-    out[name] = per
+        if m and sites:
+            sites[-1].append(int(m.group(1)))
+    out[name] = {"per_sweep": [sum(x) for x in sites], "per_site": sites}
 json.dump(out, open("ref_sweep_ndav.json", "w"), indent=1)
 print(out)
 PY

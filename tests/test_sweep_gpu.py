@@ -177,6 +177,37 @@ def test_davidson_starts_from_the_previous_site(gpu, chain, sym):
     assert "guess" in a.tm and a.tm["guess"] < a.tm["eigs"]
 
 
+def _ref_ndav(name):
+    import json
+
+    return json.load(open(os.path.join(GOLDEN, "ref_sweep_ndav.json")))[name]
+
+
+@pytest.mark.parametrize("name,chain,sym,n_sweeps", [("n2_m200", ("chain_n2su2", "n2c"), "su2", 2),
+                                                     ("h10_m500", ("chain_h10sz", "h10c"), "sz", 2),
+                                                     ("hubbard_m500", ("chain_hubu2", "hubc"), "sz", 4)])
+def test_davidson_iteration_counts_are_the_references(gpu, name, chain, sym, n_sweeps):
+    """same starting vector, same algorithm, same threshold -> the SAME number of H.psi per site as block2 printed for the run
+    of the chain ("Ndav =", tests/golden/ref_sweep_ndav.json from make_ref_ndav.sh), at every site but the very first (where
+    block2 starts from its random MPS, this loop from the diagonal); one iteration of slack at a site that stops at the
+    threshold"""
+    from block2_preview_amd.sweep import DMRG, ChainFixture
+
+    fx = ChainFixture(os.path.join(GOLDEN, *chain))
+    dm = DMRG(fx, sym)
+    dm.init_environments()
+    ref = _ref_ndav(name)["per_site"]
+    for isw in range(n_sweeps):
+        fwd = isw % 2 == 0
+        dm.sweep(isw, fwd)
+        order = range(dm.n_sites - 1) if fwd else range(dm.n_sites - 2, -1, -1)
+        mine = [dm.ndav[(isw, i)] for i in order]
+        assert len(mine) == len(ref[isw])
+        diff = [abs(a - b) for k, (a, b) in enumerate(zip(mine, ref[isw])) if (isw, k) != (0, 0)]
+        print(name, "sweep", isw, "H.psi per site", mine, "reference", ref[isw])
+        assert max(diff) <= 1 and sum(1 for x in diff if x) <= 2
+
+
 def test_sum_mpo_sweep_carries_the_wavefunction(gpu):
     """the 2-rank sum-MPO run: rank 0's carried wavefunction starts every site's Davidson over the summed plans"""
     from block2_preview_amd.sweep import ChainFixture, SumMPODMRG
@@ -293,6 +324,9 @@ def test_cr2_svp_m250_energy_gate(gpu):
     assert bonds == 120 and same == 120 and spec < 1e-6
     starts = [v[0] for v in dm.guess_log.values()]
     assert starts.count("diagonal") == 1 and starts.count("same") == 2 and starts.count("previous") == 120
+    nd = [sum(v for k, v in dm.ndav.items() if k[0] == isw) for isw in range(3)]
+    print("H.psi per sweep", nd, "reference", _ref_ndav("cr2_m250")["per_sweep"])  # 7215 / 1512 / 1465 against 7221 / 1519 / 1469
+    assert all(abs(a - b) <= 0.01 * b for a, b in zip(nd, _ref_ndav("cr2_m250")["per_sweep"]))
 
 
 def test_cr2_svp_m500_energy_gate(gpu):
