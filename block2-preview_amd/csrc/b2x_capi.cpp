@@ -83,7 +83,7 @@ void pool_trim_locked(size_t keep_bytes) {
 // itself holds are given back first — the buffer pool, then the parked plans of the compiled-plan cache (their work lists) —
 // and the allocation is retried.  (b2x_trim does the same on request, for other allocators of the process.)
 static size_t reclaim_cached_plans(); // defined behind the plan cache
-static size_t vec_cache_flush();      // defined with b2x_device_alloc
+static size_t vec_cache_flush();      // defined with cached_alloc below
 static hipError_t dev_malloc(void **out, size_t bytes) {
     hipError_t e = hipMalloc(out, bytes);
     if (e == hipSuccess)
@@ -108,6 +108,112 @@ static hipError_t dev_malloc(void **out, size_t bytes) {
         (void)hipGetLastError();
     return e;
 }
+// cached_alloc / cached_free (b2x_device_alloc / b2x_device_free and the library's own work lists) keep freed vectors for the next request of the same size class.  A sweep allocates and
+// frees the same handful of sizes at every site (enlarged and rotated blocks, the operator arena, psi-sized vectors), and a
+// hipMalloc of tens of MB costs about a millisecond, a hipFree a device-wide wait: of the 35 ms an H10 M=500 site took on the
+// host, 8 were these calls (tools/sweep_profile.py).  Size classes are 1/8 octave wide (<= 12.5 % slack behind a vector); a
+// buffer is parked only after the device is idle (what hipFree waits for as well), so a parked buffer has no reader left.
+// B2X_VEC_CACHE_MB caps the parked bytes (default 1/16 of the card, 0 = off); the oldest parked buffers go first; an
+// allocation that fails anywhere in the library flushes the cache before it gives up (dev_malloc), b2x_trim flushes it too.
+namespace {
+struct ParkedVec {
+    void *p;
+    uint64_t seq;
+};
+std::mutex g_vc_mu;
+std::multimap<size_t, ParkedVec> g_vc_free;      // parked buffers by capacity
+std::unordered_map<void *, size_t> g_vc_live;   // capacity of every vector handed out
+size_t g_vc_bytes = 0;
+uint64_t g_vc_seq = 0;
+size_t vec_cache_cap() {
+    static const size_t cap = []() -> size_t {
+        if (const char *e = getenv("B2X_VEC_CACHE_MB"))
+            return (size_t)atoll(e) << 20;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess)
+            (void)hipGetLastError(), tot = (size_t)64 << 30;
+        return tot / 16;
+    }();
+    return cap;
+}
+size_t vec_class(size_t bytes) {
+    if (bytes <= 4096)
+        return 4096;
+    const int lg = 63 - __builtin_clzll((unsigned long long)bytes);
+    const size_t step = (size_t)1 << (lg - 3);
+    return (bytes + step - 1) & ~(step - 1);
+}
+} // namespace
+static size_t vec_cache_flush() {
+    std::vector<void *> out;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_vc_mu);
+        for (auto &kv : g_vc_free)
+            out.push_back(kv.second.p), bytes += kv.first;
+        g_vc_free.clear();
+        g_vc_bytes = 0;
+    }
+    for (void *p : out)
+        (void)hipFree(p);
+    return bytes;
+}
+static hipError_t cached_alloc(void **out, size_t bytes) {
+    const size_t cap = vec_class(bytes ? bytes : 8);
+    if (vec_cache_cap() == 0 || cap > vec_cache_cap() / 4) // never parked: exactly the bytes asked for (a 90 GB arena gets no 6 GB of slack)
+        return dev_malloc(out, bytes ? bytes : 8);
+    {
+        std::lock_guard<std::mutex> lk(g_vc_mu);
+        auto it = g_vc_free.find(cap);
+        if (it != g_vc_free.end()) {
+            *out = it->second.p;
+            g_vc_free.erase(it);
+            g_vc_bytes -= cap;
+            g_vc_live[*out] = cap;
+            return hipSuccess;
+        }
+    }
+    hipError_t e = dev_malloc(out, cap);
+    if (e != hipSuccess)
+        return e;
+    std::lock_guard<std::mutex> lk(g_vc_mu);
+    g_vc_live[*out] = cap;
+    return hipSuccess;
+}
+static hipError_t cached_free(void *dptr) {
+    if (!dptr)
+        return hipSuccess;
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_vc_mu);
+        auto it = g_vc_live.find(dptr);
+        if (it != g_vc_live.end())
+            cap = it->second, g_vc_live.erase(it);
+    }
+    if (cap == 0 || vec_cache_cap() == 0 || cap > vec_cache_cap() / 4) // not from cached_alloc, or too big to park
+        return hipFree(dptr);
+    hipError_t e = hipDeviceSynchronize(); // (hipFree's own guarantee: nothing on the device still reads the vector)
+    if (e != hipSuccess)
+        return e;
+    std::vector<void *> evict;
+    {
+        std::lock_guard<std::mutex> lk(g_vc_mu);
+        g_vc_free.emplace(cap, ParkedVec{dptr, g_vc_seq++});
+        g_vc_bytes += cap;
+        while (g_vc_bytes > vec_cache_cap()) { // oldest first
+            auto old = g_vc_free.begin();
+            for (auto it = g_vc_free.begin(); it != g_vc_free.end(); ++it)
+                if (it->second.seq < old->second.seq)
+                    old = it;
+            evict.push_back(old->second.p);
+            g_vc_bytes -= old->first;
+            g_vc_free.erase(old);
+        }
+    }
+    for (void *p : evict)
+        (void)hipFree(p);
+    return hipSuccess;
+}
 namespace {
 hipError_t pool_alloc(void **out, size_t bytes, size_t *got) {
     {
@@ -123,13 +229,13 @@ hipError_t pool_alloc(void **out, size_t bytes, size_t *got) {
         }
     }
     *got = bytes;
-    return dev_malloc(out, bytes);
+    return bytes < ((size_t)64 << 20) ? cached_alloc(out, bytes) : dev_malloc(out, bytes);
 }
 void pool_free(void *p, size_t bytes) {
     if (!p)
         return;
-    if (pool_cap_bytes() == 0 || bytes < ((size_t)64 << 20) || bytes > pool_cap_bytes()) { // small buffers: not worth keeping
-        (void)hipFree(p);
+    if (pool_cap_bytes() == 0 || bytes < ((size_t)64 << 20) || bytes > pool_cap_bytes()) { // small buffers: the vector cache's business
+        (void)cached_free(p);
         return;
     }
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -238,24 +344,24 @@ static void plan_free(b2x_plan *p) {
     plan_unbind(p);
     for (int k = 0; k < kNumClasses; k++) {
         if (p->d_parts[k])
-            (void)hipFree(p->d_parts[k]);
+            (void)cached_free(p->d_parts[k]);
         if (p->d_items[k])
-            (void)hipFree(p->d_items[k]);
+            (void)cached_free(p->d_items[k]);
     }
     if (p->d_tiles)
-        (void)hipFree(p->d_tiles);
+        (void)cached_free(p->d_tiles);
     if (p->d_pairs)
-        (void)hipFree(p->d_pairs);
+        (void)cached_free(p->d_pairs);
     if (p->d_gsegs)
-        (void)hipFree(p->d_gsegs);
+        (void)cached_free(p->d_gsegs);
     if (p->d_gitems)
-        (void)hipFree(p->d_gitems);
+        (void)cached_free(p->d_gitems);
     if (p->d_gtiles)
-        (void)hipFree(p->d_gtiles);
+        (void)cached_free(p->d_gtiles);
     if (p->d_sum_work)
-        (void)hipFree(p->d_sum_work);
+        (void)cached_free(p->d_sum_work);
     if (p->d_sum_entries)
-        (void)hipFree(p->d_sum_entries);
+        (void)cached_free(p->d_sum_entries);
     if (p->aux_stream)
         (void)hipStreamDestroy(p->aux_stream);
     if (p->ev_fork)
@@ -272,7 +378,7 @@ template <typename T> static int upload(T **dst, const std::vector<T> &src) {
     if (src.empty())
         return B2X_OK;
     t_upload_bytes += src.size() * sizeof(T);
-    if (dev_malloc((void **)dst, src.size() * sizeof(T)) != hipSuccess)
+    if (cached_alloc((void **)dst, src.size() * sizeof(T)) != hipSuccess) // (freed with cached_free: the lists of the next plan reuse them)
         return fail(B2X_ERR_NOMEM, "hipMalloc(work lists): out of device memory");
     HIPCHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return B2X_OK;
@@ -445,9 +551,9 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
                     rc = fail(B2X_ERR_DEVICE, std::string("operator pre-sums: ") + hipGetErrorString(e));
             }
             if (dw)
-                (void)hipFree(dw);
+                (void)cached_free(dw);
             if (de)
-                (void)hipFree(de);
+                (void)cached_free(de);
         }
     }
     if (rc != B2X_OK) {
@@ -491,75 +597,11 @@ int b2x_device_sync(void) {
     HIPCHK(hipDeviceSynchronize());
     return B2X_OK;
 }
-// b2x_device_alloc / b2x_device_free keep freed vectors for the next request of the same size class.  A sweep allocates and
-// frees the same handful of sizes at every site (enlarged and rotated blocks, the operator arena, psi-sized vectors), and a
-// hipMalloc of tens of MB costs about a millisecond, a hipFree a device-wide wait: of the 35 ms an H10 M=500 site took on the
-// host, 8 were these calls (tools/sweep_profile.py).  Size classes are 1/8 octave wide (<= 12.5 % slack behind a vector); a
-// buffer is parked only after the device is idle (what hipFree waits for as well), so a parked buffer has no reader left.
-// B2X_VEC_CACHE_MB caps the parked bytes (default 1/16 of the card, 0 = off); the oldest parked buffers go first; an
-// allocation that fails anywhere in the library flushes the cache before it gives up (dev_malloc), b2x_trim flushes it too.
-namespace {
-struct ParkedVec {
-    void *p;
-    uint64_t seq;
-};
-std::mutex g_vc_mu;
-std::multimap<size_t, ParkedVec> g_vc_free;      // parked buffers by capacity
-std::unordered_map<void *, size_t> g_vc_live;   // capacity of every vector handed out
-size_t g_vc_bytes = 0;
-uint64_t g_vc_seq = 0;
-size_t vec_cache_cap() {
-    static const size_t cap = []() -> size_t {
-        if (const char *e = getenv("B2X_VEC_CACHE_MB"))
-            return (size_t)atoll(e) << 20;
-        size_t fr = 0, tot = 0;
-        if (hipMemGetInfo(&fr, &tot) != hipSuccess)
-            (void)hipGetLastError(), tot = (size_t)64 << 30;
-        return tot / 16;
-    }();
-    return cap;
-}
-size_t vec_class(size_t bytes) {
-    if (bytes <= 4096)
-        return 4096;
-    const int lg = 63 - __builtin_clzll((unsigned long long)bytes);
-    const size_t step = (size_t)1 << (lg - 3);
-    return (bytes + step - 1) & ~(step - 1);
-}
-} // namespace
-static size_t vec_cache_flush() {
-    std::vector<void *> out;
-    size_t bytes = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_vc_mu);
-        for (auto &kv : g_vc_free)
-            out.push_back(kv.second.p), bytes += kv.first;
-        g_vc_free.clear();
-        g_vc_bytes = 0;
-    }
-    for (void *p : out)
-        (void)hipFree(p);
-    return bytes;
-}
 int b2x_device_alloc(void **dptr, size_t bytes) {
     if (!dptr)
         return fail(B2X_ERR_INVALID, "b2x_device_alloc: null argument");
-    const size_t cap = vec_class(bytes ? bytes : 8);
-    {
-        std::lock_guard<std::mutex> lk(g_vc_mu);
-        auto it = g_vc_free.find(cap);
-        if (it != g_vc_free.end()) {
-            *dptr = it->second.p;
-            g_vc_free.erase(it);
-            g_vc_bytes -= cap;
-            g_vc_live[*dptr] = cap;
-            return B2X_OK;
-        }
-    }
-    if (dev_malloc(dptr, cap) != hipSuccess)
+    if (cached_alloc(dptr, bytes) != hipSuccess)
         return fail(B2X_ERR_NOMEM, "b2x_device_alloc: out of device memory");
-    std::lock_guard<std::mutex> lk(g_vc_mu);
-    g_vc_live[*dptr] = cap;
     return B2X_OK;
 }
 int b2x_trim(uint64_t *bytes_released) {
@@ -578,37 +620,7 @@ int b2x_trim(uint64_t *bytes_released) {
     return B2X_OK;
 }
 int b2x_device_free(void *dptr) {
-    if (!dptr)
-        return B2X_OK;
-    size_t cap = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_vc_mu);
-        auto it = g_vc_live.find(dptr);
-        if (it != g_vc_live.end())
-            cap = it->second, g_vc_live.erase(it);
-    }
-    if (cap == 0 || vec_cache_cap() == 0 || cap > vec_cache_cap() / 4) { // not from b2x_device_alloc, or too big to park
-        HIPCHK(hipFree(dptr));
-        return B2X_OK;
-    }
-    HIPCHK(hipDeviceSynchronize()); // (hipFree's own guarantee: nothing on the device still reads the vector)
-    std::vector<void *> evict;
-    {
-        std::lock_guard<std::mutex> lk(g_vc_mu);
-        g_vc_free.emplace(cap, ParkedVec{dptr, g_vc_seq++});
-        g_vc_bytes += cap;
-        while (g_vc_bytes > vec_cache_cap()) { // oldest first
-            auto old = g_vc_free.begin();
-            for (auto it = g_vc_free.begin(); it != g_vc_free.end(); ++it)
-                if (it->second.seq < old->second.seq)
-                    old = it;
-            evict.push_back(old->second.p);
-            g_vc_bytes -= old->first;
-            g_vc_free.erase(old);
-        }
-    }
-    for (void *p : evict)
-        (void)hipFree(p);
+    HIPCHK(cached_free(dptr));
     return B2X_OK;
 }
 int b2x_memcpy_h2d(void *dst, const void *src, size_t bytes) {
@@ -642,7 +654,7 @@ int b2x_arena_create(b2x_arena **out, size_t n_ranges, const double *const *host
         tot += lens[i];
     }
     a->len = tot, a->cap = tot + kSlackElems, a->owned = true;
-    hipError_t e = dev_malloc((void **)&a->dev, a->cap * sizeof(double));
+    hipError_t e = cached_alloc((void **)&a->dev, a->cap * sizeof(double));
     if (e == hipSuccess)
         e = fill_tail(a->dev + tot, kSlackElems);
     if (e != hipSuccess) {
@@ -652,7 +664,7 @@ int b2x_arena_create(b2x_arena **out, size_t n_ranges, const double *const *host
     for (size_t k = 0; k < n_ranges; k++) {
         e = hipMemcpy(a->dev + a->offs[k], a->host_bases[k], a->host_lens[k] * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) {
-            (void)hipFree(a->dev);
+            (void)cached_free(a->dev);
             delete a;
             return fail(B2X_ERR_DEVICE, std::string("hipMemcpy(arena): ") + hipGetErrorString(e));
         }
@@ -700,7 +712,7 @@ int b2x_arena_destroy(b2x_arena *a) {
     if (!a)
         return B2X_OK;
     if (a->owned && a->dev)
-        (void)hipFree(a->dev);
+        (void)cached_free(a->dev);
     delete a;
     return B2X_OK;
 }
@@ -1114,9 +1126,9 @@ int b2x_diag_build(const b2x_arena *arena, size_t n_terms, const b2x_diag_term *
             rc = fail(B2X_ERR_DEVICE, std::string("b2x_diag_build: ") + hipGetErrorString(e));
     }
     if (dc)
-        (void)hipFree(dc);
+        (void)cached_free(dc);
     if (dt)
-        (void)hipFree(dt);
+        (void)cached_free(dt);
     if (!on_device && dd != diag && dd)
         (void)hipFree(dd);
     return rc;
@@ -1166,9 +1178,9 @@ int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term
             rc = fail(B2X_ERR_DEVICE, std::string("b2x_outer_build: ") + hipGetErrorString(e));
     }
     if (dw)
-        (void)hipFree(dw);
+        (void)cached_free(dw);
     if (de)
-        (void)hipFree(de);
+        (void)cached_free(de);
     if (!on_device) {
         if (d_out && d_out != out)
             (void)hipFree(d_out);
