@@ -1195,9 +1195,9 @@ static double *g_dot_partial = nullptr, *g_dot_out = nullptr;
 static double *g_dot_host = nullptr; // pinned: the few result doubles of every dot product cross PCIe without a staging copy
 static int dot_scratch() {
     if (!g_dot_partial) {
-        HIPCHK(hipMalloc((void **)&g_dot_partial, 64 * 256 * sizeof(double)));
-        HIPCHK(hipMalloc((void **)&g_dot_out, 64 * sizeof(double)));
-        HIPCHK(hipHostMalloc((void **)&g_dot_host, 64 * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&g_dot_partial, 128 * 256 * sizeof(double)));
+        HIPCHK(hipMalloc((void **)&g_dot_out, 128 * sizeof(double)));
+        HIPCHK(hipHostMalloc((void **)&g_dot_host, 128 * sizeof(double), hipHostMallocDefault));
     }
     return B2X_OK;
 }
@@ -1213,6 +1213,20 @@ int b2x_vec_multi_dot(const double *const *vs, int nv, const double *x, size_t n
     HIPCHK(hipMemcpyAsync(g_dot_host, g_dot_out, nv * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(host_result, g_dot_host, nv * sizeof(double));
+    return B2X_OK;
+}
+int b2x_vec_pair_dots(const double *const *us, const double *const *vs, int n_pairs, size_t n, double *host_result,
+                      void *stream) {
+    if (n_pairs < 1 || n_pairs > 128 || !us || !vs || !host_result)
+        return fail(B2X_ERR_INVALID, "b2x_vec_pair_dots: need 1 <= n_pairs <= 128");
+    int rc = dot_scratch();
+    if (rc != B2X_OK)
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(launch_pairdot(us, vs, n_pairs, n, g_dot_partial, g_dot_out, st));
+    HIPCHK(hipMemcpyAsync(g_dot_host, g_dot_out, n_pairs * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(host_result, g_dot_host, n_pairs * sizeof(double));
     return B2X_OK;
 }
 int b2x_vec_dot(const double *x, const double *y, size_t n, double *host_result, void *stream) {
@@ -1240,7 +1254,14 @@ int b2x_vec_precondition(double *q, const double *diag, double shift, size_t n, 
     return B2X_OK;
 }
 int b2x_vec_olsen_prepare(double *q, double *t, const double *c, const double *diag, double ld, size_t n, void *stream) {
-    HIPCHK(launch_olsen(q, t, c, diag, ld, n, (hipStream_t)stream));
+    HIPCHK(launch_olsen(q, q, t, c, diag, ld, n, (hipStream_t)stream));
+    return B2X_OK;
+}
+int b2x_vec_olsen_prepare_to(const double *q, double *q_out, double *t, const double *c, const double *diag, double ld, size_t n,
+                             void *stream) {
+    if (!q || !q_out || !t || !c || !diag)
+        return fail(B2X_ERR_INVALID, "b2x_vec_olsen_prepare_to: null argument");
+    HIPCHK(launch_olsen(q, q_out, t, c, diag, ld, n, (hipStream_t)stream));
     return B2X_OK;
 }
 int b2x_vec_lincomb(const double *const *vs, int nv, const double *coef, double *y, size_t n, void *stream) {

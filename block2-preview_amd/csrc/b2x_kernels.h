@@ -28,7 +28,10 @@ hipError_t launch_diag(const DiagComp *comps, uint32_t n_comps, const DiagTermD 
 hipError_t launch_axpy(double a, const double *x, double *y, size_t n, hipStream_t st);
 hipError_t launch_scal(double a, double *x, size_t n, hipStream_t st);
 hipError_t launch_precond(double *q, const double *diag, double shift, size_t n, hipStream_t st);
-hipError_t launch_olsen(double *q, double *t, const double *c, const double *diag, double ld, size_t n, hipStream_t st);
+hipError_t launch_olsen(const double *q, double *q_out, double *t, const double *c, const double *diag, double ld, size_t n,
+                        hipStream_t st);
+hipError_t launch_pairdot(const double *const *us, const double *const *vs, int np, size_t n, double *partial, double *out,
+                          hipStream_t st);
 hipError_t launch_lincomb(const double *const *vs, const double *coef, int nv, double *y, size_t n, hipStream_t st);
 int multidot_blocks(size_t n);
 hipError_t launch_multidot(const double *const *vs, int nv, const double *x, size_t n, double *partial, double *out,

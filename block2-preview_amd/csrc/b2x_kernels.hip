@@ -872,12 +872,14 @@ __global__ void vec_precond_k(double *q, const double *diag, double shift, size_
             q[i] /= d;
     }
 }
-__global__ void vec_olsen_k(double *q, double *t, const double *c, const double *diag, double ld, size_t n) {
+// (qo == q: in place, the reference's form; qo != q leaves the residual itself intact for the fused dot products of the
+// Davidson step)
+__global__ void vec_olsen_k(const double *q, double *qo, double *t, const double *c, const double *diag, double ld, size_t n) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         double d = ld - diag[i], tv = c[i], qv = q[i];
         if (fabs(d) > 1e-12)
             tv /= d, qv /= d;
-        t[i] = tv, q[i] = qv;
+        t[i] = tv, qo[i] = qv;
     }
 }
 struct VecPtrs {
@@ -901,6 +903,29 @@ __global__ __launch_bounds__(256) void vec_multidot_k(VecPtrs vp, int nv, const 
     double s = 0.0;
     for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         s += vp.p[j][i] * x[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            sh[threadIdx.x] += sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        partial[(size_t)j * gridDim.x + blockIdx.x] = sh[0];
+}
+// the same for independent pairs: partial[j * nblk + b] = share of <u_j, v_j> (one launch and one host round trip for all
+// the dot products of a Davidson step; pointers only: 2 KB of kernel arguments for 128 pairs)
+struct PairPtrs {
+    const double *u[128];
+    const double *v[128];
+};
+__global__ __launch_bounds__(256) void vec_pairdot_k(PairPtrs pp, size_t n, double *partial) {
+    __shared__ double sh[256];
+    const int j = blockIdx.y;
+    const double *u = pp.u[j], *v = pp.v[j];
+    double s = 0.0;
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        s += u[i] * v[i];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
@@ -1041,8 +1066,9 @@ hipError_t launch_precond(double *q, const double *diag, double shift, size_t n,
     hipLaunchKernelGGL(vec_precond_k, dim3(vec_grid(n)), dim3(256), 0, st, q, diag, shift, n);
     return hipGetLastError();
 }
-hipError_t launch_olsen(double *q, double *t, const double *c, const double *diag, double ld, size_t n, hipStream_t st) {
-    hipLaunchKernelGGL(vec_olsen_k, dim3(vec_grid(n)), dim3(256), 0, st, q, t, c, diag, ld, n);
+hipError_t launch_olsen(const double *q, double *q_out, double *t, const double *c, const double *diag, double ld, size_t n,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(vec_olsen_k, dim3(vec_grid(n)), dim3(256), 0, st, q, q_out, t, c, diag, ld, n);
     return hipGetLastError();
 }
 hipError_t launch_lincomb(const double *const *vs, const double *coef, int nv, double *y, size_t n, hipStream_t st) {
@@ -1064,6 +1090,17 @@ hipError_t launch_multidot(const double *const *vs, int nv, const double *x, siz
     int nb = multidot_blocks(n);
     hipLaunchKernelGGL(vec_multidot_k, dim3(nb, nv), dim3(256), 0, st, vp, nv, x, n, partial);
     hipLaunchKernelGGL(vec_multidot_final_k, dim3(nv), dim3(256), 0, st, partial, nb, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pairdot(const double *const *us, const double *const *vs, int np, size_t n, double *partial, double *out,
+                          hipStream_t st) {
+    PairPtrs pp;
+    for (int j = 0; j < np; j++)
+        pp.u[j] = us[j], pp.v[j] = vs[j];
+    int nb = multidot_blocks(n);
+    hipLaunchKernelGGL(vec_pairdot_k, dim3(nb, np), dim3(256), 0, st, pp, n, partial);
+    hipLaunchKernelGGL(vec_multidot_final_k, dim3(np), dim3(256), 0, st, partial, nb, out);
     return hipGetLastError();
 }
 

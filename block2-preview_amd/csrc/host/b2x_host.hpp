@@ -841,6 +841,7 @@ struct IterativeMatrixFunctions {
         for (int i = 0; i < k; i++)
             ensure(i);
         double *q = mk(), *t = mk(), *x = mk(); // residual / work vector / current Ritz vector
+        double *q2 = mk();                      // preconditioned residual of the fused step (below)
         std::vector<double *> dfl_b, dfl_s;     // work vectors of a deflation step
         auto dot = [&](const double *u, const double *v) {
             double r;
@@ -862,7 +863,7 @@ struct IterativeMatrixFunctions {
         // v -= sum_{j < m} <b_j, v> b_j: ONE multi-dot and ONE linear combination per pass (the reference's loop of m
         // dot / axpy pairs, :1143-1144, costs m launches and m host round trips on a device), two passes for the
         // orthogonality a one-pass classical Gram-Schmidt loses.  Result in `v` (the work vector w is swapped in).
-        std::vector<double> gs_c(M + 1);
+        std::vector<double> gs_c(M + 2);
         auto orthogonalise = [&](double *&v, double *&w, int m_) {
             for (int pass = 0; pass < 2 && m_ > 0; pass++) {
                 std::vector<const double *> ptrs(bs.begin(), bs.begin() + m_);
@@ -921,6 +922,11 @@ struct IterativeMatrixFunctions {
             check(b2x_vec_lincomb(ps.data(), m + 1, coef.data(), q, n, nullptr));
         };
         static const bool prof = getenv("B2X_DAV_PROFILE") != nullptr;
+        const char *fused_env = getenv("B2X_DAV_FUSED");
+        const bool fused_ok = nor == 0 && nwg == 0 && !(davidson_type & DavidsonTypes::DavidsonPrecond) &&
+                              !(davidson_type & DavidsonTypes::NoPrecond) && !(fused_env && fused_env[0] == '0');
+        std::vector<const double *> fu, fv; // pairs of the fused dot products, and their results
+        std::vector<double> fr;
         double t_op = 0, t_eig = 0;
         auto now = []() { return std::chrono::steady_clock::now(); };
         auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -984,11 +990,31 @@ struct IterativeMatrixFunctions {
             }
             const int ick = idx[ck];
             ritz_residual(ick);
-            project_ors(q);
-            qq = dot(q, q);
+            // The usual step (Olsen preconditioner, no projected-out states, no collapse due) in THREE host round trips
+            // instead of six: the residual norm, the two Olsen products and the projections of the preconditioned residual
+            // q2 and of t on the basis are ONE b2x_vec_pair_dots; the Olsen correction and the first Gram-Schmidt pass are
+            // then ONE linear combination (both are linear in q2 and t: <b_j, q2 - g t> = <b_j, q2> - g <b_j, t>), the second
+            // pass and the norm of the new vector one more pair-dot and one more combination.  Same subspace as the
+            // step-by-step form below up to rounding (B2X_DAV_FUSED=0 selects that form; tools/davidson_overhead.py).
+            const bool fused = fused_ok && m < deflation_max_size && m + 2 <= 64 && 2 * m + 3 <= 128;
+            if (fused) {
+                check(b2x_vec_olsen_prepare_to(q, q2, t, x, aa_dev, ld[ick], n, nullptr));
+                fu.assign({q, q2, t}), fv.assign({q, x, x});
+                for (int j = 0; j < m; j++)
+                    fu.push_back(bs[j]), fv.push_back(q2);
+                for (int j = 0; j < m; j++)
+                    fu.push_back(bs[j]), fv.push_back(t);
+                fr.resize(3 + 2 * (size_t)m);
+                check(b2x_vec_pair_dots(fu.data(), fv.data(), 3 + 2 * m, n, fr.data(), nullptr));
+                qq = fr[0];
+            } else {
+                project_ors(q);
+                qq = dot(q, q);
+            }
             if (iprint)
                 printf("%6d%6d%6d%15.8f%13.2e\n", xiter, m, ck, ld[ick], std::fabs(qq));
-            if (davidson_type & DavidsonTypes::DavidsonPrecond) // davidson_precondition (:66-72)
+            if (fused) {
+            } else if (davidson_type & DavidsonTypes::DavidsonPrecond) // davidson_precondition (:66-72)
                 check(b2x_vec_precondition(q, aa_dev, ld[ick], n, nullptr));
             else if (!(davidson_type & DavidsonTypes::NoPrecond)) { // olsen_precondition (:93-108)
                 check(b2x_vec_olsen_prepare(q, t, x, aa_dev, ld[ick], n, nullptr));
@@ -1029,12 +1055,45 @@ struct IterativeMatrixFunctions {
                         H[(size_t)j * M + j] = th[j], alpha[(size_t)j * keep + j] = 1.0, idx[j] = j;
                     m = msig = keep;
                 }
-                orthogonalise(q, t, m);
-                project_ors(q);
-                check(b2x_vec_scal(1.0 / std::sqrt(dot(q, q)), q, n, nullptr));
-                ensure(m);
-                check(b2x_vec_copy(q, bs[m], n, nullptr));
-                m++;
+                bool appended = false;
+                if (fused) {
+                    // v1 = q2 - g t - sum_j (<b_j, q2> - g <b_j, t>) b_j   (the residual q is free: v1 goes there)
+                    const double g = fr[1] / fr[2];
+                    std::vector<const double *> ptrs(bs.begin(), bs.begin() + m);
+                    for (int j = 0; j < m; j++)
+                        gs_c[j] = -(fr[3 + j] - g * fr[3 + m + j]);
+                    ptrs.push_back(q2), ptrs.push_back(t);
+                    gs_c[m] = 1.0, gs_c[m + 1] = -g;
+                    check(b2x_vec_lincomb(ptrs.data(), m + 2, gs_c.data(), q, n, nullptr));
+                    // second pass and the norm: <b_j, v1> and <v1, v1> together; |v1 - sum c_j b_j|^2 = <v1, v1> - sum c_j^2
+                    // for an orthonormal basis (the c_j are rounding-sized after the first pass: no cancellation)
+                    fu.assign(bs.begin(), bs.begin() + m), fv.assign((size_t)m, q);
+                    fu.push_back(q), fv.push_back(q);
+                    fr.resize((size_t)m + 1);
+                    check(b2x_vec_pair_dots(fu.data(), fv.data(), m + 1, n, fr.data(), nullptr));
+                    double nrm2 = fr[m];
+                    for (int j = 0; j < m; j++)
+                        nrm2 -= fr[j] * fr[j];
+                    if (nrm2 > 1e-24 * std::fabs(fr[m]) && nrm2 > 0) {
+                        const double inv = 1.0 / std::sqrt(nrm2);
+                        ptrs.assign(bs.begin(), bs.begin() + m);
+                        for (int j = 0; j < m; j++)
+                            gs_c[j] = -fr[j] * inv;
+                        ptrs.push_back(q);
+                        gs_c[m] = inv;
+                        ensure(m);
+                        check(b2x_vec_lincomb(ptrs.data(), m + 1, gs_c.data(), bs[m], n, nullptr));
+                        m++, appended = true;
+                    } // (else: the new direction lies in the subspace to rounding; finish it the careful way)
+                }
+                if (!appended) {
+                    orthogonalise(q, t, m);
+                    project_ors(q);
+                    check(b2x_vec_scal(1.0 / std::sqrt(dot(q, q)), q, n, nullptr));
+                    ensure(m);
+                    check(b2x_vec_copy(q, bs[m], n, nullptr));
+                    m++;
+                }
             }
             if (xiter == soft_max_iter)
                 break;

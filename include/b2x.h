@@ -267,6 +267,15 @@ int b2x_vec_precondition(double *q, const double *diag, double shift, size_t n, 
  * q += -(c.q)/(c.t) * t using b2x_vec_multi_dot + b2x_vec_axpy.) */
 int b2x_vec_olsen_prepare(double *q, double *t, const double *c, const double *diag, double ld, size_t n,
                           void *stream);
+/* the same with the scaled residual written to q_out and q left as it is (q_out == q: b2x_vec_olsen_prepare): lets the
+ * Davidson step take |q|^2, c.q_out, c.t and the projections of q_out and t on the basis from ONE b2x_vec_pair_dots */
+int b2x_vec_olsen_prepare_to(const double *q, double *q_out, double *t, const double *c, const double *diag, double ld,
+                             size_t n, void *stream);
+/* result[j] = <us[j], vs[j]> for j < n_pairs <= 128 (host arrays of device pointers): every dot product of a Davidson step
+ * in one launch and one host round trip (the reference's loop of dot calls, iterative_matrix_functions.hpp:1143-1144,
+ * would be one device synchronisation each) */
+int b2x_vec_pair_dots(const double *const *us, const double *const *vs, int n_pairs, size_t n, double *host_result,
+                      void *stream);
 /* gram[j] = <vs[j], x> for j < nv; vs = nv device pointers (host array of device pointers) */
 int b2x_vec_multi_dot(const double *const *vs, int nv, const double *x, size_t n, double *host_result,
                       void *stream);
