@@ -1144,11 +1144,14 @@ int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term
     std::vector<OWork> work;
     std::vector<OEntry> entries;
     std::string err;
+    static const bool dbg = getenv("B2X_PLAN_DEBUG") != nullptr; // (development aid: host clock of the three phases, on stderr)
+    const auto t_0 = std::chrono::steady_clock::now();
     int rc = compile_outer(n_terms, terms, in_len, out_len, arena->len, work, entries, err);
     if (rc != B2X_OK)
         return fail(rc, "b2x_outer_build: " + err);
     if (work.empty())
         return B2X_OK;
+    const auto t_1 = std::chrono::steady_clock::now();
     hipStream_t st = (hipStream_t)stream;
     OWork *dw = nullptr;
     OEntry *de = nullptr;
@@ -1176,6 +1179,12 @@ int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term
             e = hipMemcpy(out, d_out, out_len * sizeof(double), hipMemcpyDeviceToHost);
         if (e != hipSuccess)
             rc = fail(B2X_ERR_DEVICE, std::string("b2x_outer_build: ") + hipGetErrorString(e));
+    }
+    if (dbg) {
+        const auto t_2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[b2x outer] terms %zu -> work %zu entries %zu: compile %.3f ms, upload + kernel + wait %.3f ms\n", n_terms,
+                work.size(), entries.size(), std::chrono::duration<double, std::milli>(t_1 - t_0).count(),
+                std::chrono::duration<double, std::milli>(t_2 - t_1).count());
     }
     if (dw)
         (void)cached_free(dw);

@@ -255,7 +255,29 @@ const std::vector<int> &wave_cuts_m(int total, int tile) {
 // Sort the output windows and merge overlapping ones into disjoint components (sectors of the output vector with a
 // common leading dimension).  `fallback` is set when the windows cannot be laid on a common grid.
 std::vector<Component> build_components(std::vector<Window> &win, bool &fallback, std::string &reason) {
-    std::stable_sort(win.begin(), win.end(), [](const Window &a, const Window &b) { return a.off < b.off; }); // (mostly pre-sorted input: the merge sort wins)
+    // stable order by offset (windows of equal offset stay in plan order).  Long lists (the 1e5..1e6 windows of a blocking or
+    // H.psi list) go through a least-significant-digit radix pass over the offsets — the same order as std::stable_sort gives,
+    // a third of its time
+    if (win.size() < 4096) {
+        std::stable_sort(win.begin(), win.end(), [](const Window &a, const Window &b) { return a.off < b.off; }); // (mostly pre-sorted input: the merge sort wins)
+    } else {
+        uint64_t top = 0;
+        for (const Window &w : win)
+            top |= w.off;
+        std::vector<Window> tmp(win.size());
+        std::vector<uint32_t> cnt;
+        const int kBits = 11;
+        for (int shift = 0; shift < 64 && (top >> shift) != 0; shift += kBits) {
+            cnt.assign(((size_t)1 << kBits) + 1, 0);
+            for (const Window &w : win)
+                cnt[((w.off >> shift) & (((uint64_t)1 << kBits) - 1)) + 1]++;
+            for (size_t d = 0; d < ((size_t)1 << kBits); d++)
+                cnt[d + 1] += cnt[d];
+            for (const Window &w : win)
+                tmp[cnt[(w.off >> shift) & (((uint64_t)1 << kBits) - 1)]++] = w;
+            win.swap(tmp);
+        }
+    }
     std::vector<Component> comps;
     size_t i = 0;
     while (i < win.size()) {
@@ -290,7 +312,10 @@ std::vector<Component> build_components(std::vector<Window> &win, bool &fallback
             bool ok = true;
             for (size_t k = i; k < j && ok; k++) {
                 uint64_t rel = win[k].off - c.base + (uint64_t)c0;
-                if ((int)(rel % (uint64_t)ld) + win[k].n > ld)
+                // (offsets inside a component nearly always fit 32 bits: a 32-bit remainder costs a third of a 64-bit one, and
+                // this loop and the next run once per window of every list)
+                const int col = rel <= 0xFFFFFFFFull ? (int)((uint32_t)rel % (uint32_t)ld) : (int)(rel % (uint64_t)ld);
+                if (col + win[k].n > ld)
                     ok = false, c0 = (int)((uint64_t)ld - (win[k].off - c.base) % (uint64_t)ld) % ld;
             }
             if (ok)
@@ -308,8 +333,13 @@ std::vector<Component> build_components(std::vector<Window> &win, bool &fallback
             c.base -= (uint64_t)c0;
             for (size_t k = i; k < j; k++) {
                 uint64_t rel = win[k].off - c.base;
-                c.rows = std::max(c.rows, (int)(rel / (uint64_t)ld) + win[k].m);
-                c.cols = std::max(c.cols, (int)(rel % (uint64_t)ld) + win[k].n);
+                int r0, cc;
+                if (rel <= 0xFFFFFFFFull)
+                    r0 = (int)((uint32_t)rel / (uint32_t)ld), cc = (int)((uint32_t)rel - (uint32_t)r0 * (uint32_t)ld);
+                else
+                    r0 = (int)(rel / (uint64_t)ld), cc = (int)(rel % (uint64_t)ld);
+                c.rows = std::max(c.rows, r0 + win[k].m);
+                c.cols = std::max(c.cols, cc + win[k].n);
             }
         }
         comps.push_back(c);
@@ -1891,6 +1921,7 @@ int compile_gemm_list(size_t n_gemms, const b2x_gemm *gemms, size_t in_len, size
 int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, size_t out_len, uint64_t arena_len,
                   std::vector<OWork> &work, std::vector<OEntry> &entries, std::string &err) {
     work.clear(), entries.clear();
+    PhaseClock pc;
     auto span = [](int64_t m, int64_t n, int64_t rs, int64_t cs, int64_t &lo, int64_t &hi) {
         // offsets touched by r*rs + c*cs, r < m, c < n (strides may be 0, never negative)
         lo = 0, hi = (m - 1) * rs + (n - 1) * cs;
@@ -1921,6 +1952,7 @@ int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, si
     }
     if (n_terms == 0)
         return B2X_OK;
+    pc.lap("o0 validate");
     std::vector<Window> win(n_terms);
     for (size_t i = 0; i < n_terms; i++)
         win[i] = Window{terms[i].c_off, terms[i].m, terms[i].n, terms[i].ldc, (uint32_t)i};
@@ -1931,76 +1963,135 @@ int compile_outer(size_t n_terms, const b2x_outer_term *terms, size_t in_len, si
         err = reason;
         return B2X_ERR_INVALID;
     }
+    pc.lap("o1 components");
+    // cells of a component: the grid cut at every window boundary.  The terms of a cell are gathered by a counting pass into
+    // one flat list (a blocking list has ~1e5 windows of a few dozen elements each, three terms per cell: a vector per cell
+    // was an allocation per cell and most of this function's time)
     std::vector<int> rb, cb;
-    std::vector<std::vector<uint32_t>> cell_terms;
+    std::vector<uint32_t> members, cell_begin, cell_fill, flat;
+    struct Span {
+        uint32_t a0, a1, b0, b1;
+    };
+    std::vector<Span> spans;
+    entries.reserve(n_terms);
+    work.reserve(n_terms / 2 + 16);
+    std::vector<int> wr0, wc0; // row / column of every window's origin inside its component (one division per window)
+    auto emit_cell = [&](const Component &c, int r_lo, int r_hi, int c_lo, int c_hi, uint32_t eb, int T) -> bool {
+        OWork w{};
+        w.out_off = c.base + (uint64_t)r_lo * c.ld + c_lo;
+        w.ld = c.ld, w.rows = r_hi - r_lo, w.cols = c_hi - c_lo;
+        w.entry_begin = eb, w.entry_end = (uint32_t)entries.size();
+        // tiles: 64 columns x rpt rows, rpt sized so that a tile carries a few thousand element-term products;
+        // a unit (one wave) takes up to 4 consecutive tiles
+        w.rpt = std::max(4, std::min(64, 256 / std::max(1, T)));
+        const uint32_t nseg = (uint32_t)ceil_div(w.cols, kOuterTileCols), nstrip = (uint32_t)ceil_div(w.rows, w.rpt);
+        const uint64_t ntile = (uint64_t)nseg * nstrip;
+        if (ntile > 0xFFFFFFFFull) {
+            err = "outer cell with more than 2^32 tiles";
+            return false;
+        }
+        const uint32_t per = ntile >= 4096 ? 4 : (ntile >= 1024 ? 2 : 1);
+        for (uint64_t t0 = 0; t0 < ntile; t0 += per) {
+            w.t_begin = (uint32_t)t0, w.t_end = (uint32_t)std::min<uint64_t>(ntile, t0 + per);
+            work.push_back(w);
+        }
+        return true;
+    };
+    auto make_entry = [&](const b2x_outer_term &t, int64_t dr, int64_t dc) {
+        OEntry e{};
+        e.a_off = t.a_off + (uint64_t)(dr * t.a_rs + dc * t.a_cs);
+        e.b_off = t.b_off + (uint64_t)(dr * t.b_rs + dc * t.b_cs);
+        e.alpha = t.alpha, e.a_rs = t.a_rs, e.a_cs = t.a_cs, e.b_rs = t.b_rs, e.b_cs = t.b_cs;
+        e.a_src = t.a_src, e.b_src = t.b_src;
+        if (t.a_src == 2) // the constant 1.0: the kernel still forms an address, keep it inside the arena
+            e.a_off = 0, e.a_rs = e.a_cs = 0;
+        if (t.b_src == 2)
+            e.b_off = 0, e.b_rs = e.b_cs = 0;
+        entries.push_back(e);
+    };
     for (const Component &c : comps) {
+        const uint32_t nw = c.w_end - c.w_begin;
+        // The usual component of a blocking list: a handful of terms that all write the SAME window (one sub-block of an
+        // enlarged operator) — one cell, the terms in plan order (the sort by offset is stable), none of the grid machinery.
+        bool same = true;
+        for (uint32_t wi = c.w_begin + 1; wi < c.w_end && same; wi++)
+            same = win[wi].off == win[c.w_begin].off && win[wi].m == win[c.w_begin].m && win[wi].n == win[c.w_begin].n;
+        if (same && win[c.w_begin].off == c.base) {
+            const uint32_t eb = (uint32_t)entries.size();
+            for (uint32_t wi = c.w_begin; wi < c.w_end; wi++)
+                make_entry(terms[win[wi].pair], 0, 0);
+            if (!emit_cell(c, 0, win[c.w_begin].m, 0, win[c.w_begin].n, eb, (int)nw))
+                return B2X_ERR_INVALID;
+            continue;
+        }
         rb.assign({0, c.rows}), cb.assign({0, c.cols});
+        wr0.resize(nw), wc0.resize(nw);
         for (uint32_t wi = c.w_begin; wi < c.w_end; wi++) {
-            uint64_t rel = win[wi].off - c.base;
-            int r0 = (int)(rel / (uint64_t)c.ld), c0 = (int)(rel % (uint64_t)c.ld);
+            const uint64_t rel = win[wi].off - c.base;
+            int r0, c0;
+            if (rel <= 0xFFFFFFFFull) // (a 32-bit division costs a third of a 64-bit one)
+                r0 = (int)((uint32_t)rel / (uint32_t)c.ld), c0 = (int)((uint32_t)rel - (uint32_t)r0 * (uint32_t)c.ld);
+            else
+                r0 = (int)(rel / (uint64_t)c.ld), c0 = (int)(rel % (uint64_t)c.ld);
+            wr0[wi - c.w_begin] = r0, wc0[wi - c.w_begin] = c0;
             rb.push_back(r0), rb.push_back(r0 + win[wi].m), cb.push_back(c0), cb.push_back(c0 + win[wi].n);
         }
         std::sort(rb.begin(), rb.end()), rb.erase(std::unique(rb.begin(), rb.end()), rb.end());
         std::sort(cb.begin(), cb.end()), cb.erase(std::unique(cb.begin(), cb.end()), cb.end());
         const size_t nr = rb.size() - 1, ncl = cb.size() - 1;
-        cell_terms.assign(nr * ncl, std::vector<uint32_t>());
         // plan order inside a cell
-        std::vector<uint32_t> members;
-        for (uint32_t wi = c.w_begin; wi < c.w_end; wi++)
-            members.push_back(wi);
-        std::sort(members.begin(), members.end(), [&](uint32_t a, uint32_t b) { return win[a].pair < win[b].pair; });
-        for (uint32_t wi : members) {
-            uint64_t rel = win[wi].off - c.base;
-            int r0 = (int)(rel / (uint64_t)c.ld), c0 = (int)(rel % (uint64_t)c.ld);
-            size_t a0 = std::lower_bound(rb.begin(), rb.end(), r0) - rb.begin();
-            size_t b0 = std::lower_bound(cb.begin(), cb.end(), c0) - cb.begin();
-            for (size_t a = a0; a < nr && rb[a] < r0 + win[wi].m; a++)
-                for (size_t b = b0; b < ncl && cb[b] < c0 + win[wi].n; b++)
-                    cell_terms[a * ncl + b].push_back(wi);
+        members.resize(nw);
+        for (uint32_t k = 0; k < nw; k++)
+            members[k] = c.w_begin + k;
+        auto by_pair = [&](uint32_t a, uint32_t b) { return win[a].pair < win[b].pair; };
+        if (!std::is_sorted(members.begin(), members.end(), by_pair))
+            std::sort(members.begin(), members.end(), by_pair);
+        spans.resize(nw);
+        cell_begin.assign(nr * ncl + 1, 0);
+        for (uint32_t k = 0; k < nw; k++) {
+            const Window &w = win[members[k]];
+            const int r0 = wr0[members[k] - c.w_begin], c0 = wc0[members[k] - c.w_begin];
+            Span sp;
+            sp.a0 = (uint32_t)(std::lower_bound(rb.begin(), rb.end(), r0) - rb.begin());
+            sp.b0 = (uint32_t)(std::lower_bound(cb.begin(), cb.end(), c0) - cb.begin());
+            sp.a1 = sp.a0, sp.b1 = sp.b0;
+            while (sp.a1 < nr && rb[sp.a1] < r0 + w.m)
+                sp.a1++;
+            while (sp.b1 < ncl && cb[sp.b1] < c0 + w.n)
+                sp.b1++;
+            spans[k] = sp;
+            for (uint32_t a = sp.a0; a < sp.a1; a++)
+                for (uint32_t b = sp.b0; b < sp.b1; b++)
+                    cell_begin[a * ncl + b + 1]++;
+        }
+        for (size_t i = 0; i < nr * ncl; i++)
+            cell_begin[i + 1] += cell_begin[i];
+        flat.resize(cell_begin[nr * ncl]);
+        cell_fill.assign(cell_begin.begin(), cell_begin.end() - 1);
+        for (uint32_t k = 0; k < nw; k++) { // (members in plan order: every cell's list comes out in plan order)
+            const Span &sp = spans[k];
+            for (uint32_t a = sp.a0; a < sp.a1; a++)
+                for (uint32_t b = sp.b0; b < sp.b1; b++)
+                    flat[cell_fill[a * ncl + b]++] = members[k];
         }
         for (size_t a = 0; a < nr; a++)
             for (size_t b = 0; b < ncl; b++) {
-                const auto &lst = cell_terms[a * ncl + b];
-                if (lst.empty())
+                const uint32_t *lst = flat.data() + cell_begin[a * ncl + b];
+                const int T = (int)(cell_begin[a * ncl + b + 1] - cell_begin[a * ncl + b]);
+                if (T == 0)
                     continue;
                 const uint32_t eb = (uint32_t)entries.size();
-                for (uint32_t wi : lst) {
-                    const b2x_outer_term &t = terms[win[wi].pair];
-                    uint64_t rel = win[wi].off - c.base;
-                    int r0 = (int)(rel / (uint64_t)c.ld), c0 = (int)(rel % (uint64_t)c.ld);
-                    const int64_t dr = rb[a] - r0, dc = cb[b] - c0; // cell origin inside the term window
-                    OEntry e{};
-                    e.a_off = t.a_off + (uint64_t)(dr * t.a_rs + dc * t.a_cs);
-                    e.b_off = t.b_off + (uint64_t)(dr * t.b_rs + dc * t.b_cs);
-                    e.alpha = t.alpha, e.a_rs = t.a_rs, e.a_cs = t.a_cs, e.b_rs = t.b_rs, e.b_cs = t.b_cs;
-                    e.a_src = t.a_src, e.b_src = t.b_src;
-                    if (t.a_src == 2) // the constant 1.0: the kernel still forms an address, keep it inside the arena
-                        e.a_off = 0, e.a_rs = e.a_cs = 0;
-                    if (t.b_src == 2)
-                        e.b_off = 0, e.b_rs = e.b_cs = 0;
-                    entries.push_back(e);
+                for (int li = 0; li < T; li++) {
+                    const uint32_t wi = lst[li];
+                    // cell origin inside the term window
+                    make_entry(terms[win[wi].pair], rb[a] - wr0[wi - c.w_begin], cb[b] - wc0[wi - c.w_begin]);
                 }
-                OWork w{};
-                w.out_off = c.base + (uint64_t)rb[a] * c.ld + cb[b];
-                w.ld = c.ld, w.rows = rb[a + 1] - rb[a], w.cols = cb[b + 1] - cb[b];
-                w.entry_begin = eb, w.entry_end = (uint32_t)entries.size();
-                // tiles: 64 columns x rpt rows, rpt sized so that a tile carries a few thousand element-term products;
-                // a unit (one wave) takes up to 4 consecutive tiles
-                const int T = (int)lst.size();
-                w.rpt = std::max(4, std::min(64, 256 / std::max(1, T)));
-                const uint32_t nseg = (uint32_t)ceil_div(w.cols, kOuterTileCols), nstrip = (uint32_t)ceil_div(w.rows, w.rpt);
-                const uint64_t ntile = (uint64_t)nseg * nstrip;
-                if (ntile > 0xFFFFFFFFull) {
-                    err = "outer cell with more than 2^32 tiles";
+                if (!emit_cell(c, rb[a], rb[a + 1], cb[b], cb[b + 1], eb, T))
                     return B2X_ERR_INVALID;
-                }
-                const uint32_t per = ntile >= 4096 ? 4 : (ntile >= 1024 ? 2 : 1);
-                for (uint64_t t0 = 0; t0 < ntile; t0 += per) {
-                    w.t_begin = (uint32_t)t0, w.t_end = (uint32_t)std::min<uint64_t>(ntile, t0 + per);
-                    work.push_back(w);
-                }
             }
     }
+    pc.lap("o2 cells");
+    pc.report();
     return B2X_OK;
 }
 

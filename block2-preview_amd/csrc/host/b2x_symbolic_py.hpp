@@ -7,6 +7,7 @@
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
+#include <chrono>
 #include <sstream>
 
 namespace b2xh {
@@ -342,6 +343,16 @@ template <typename S> py::tuple sym_rotate(const py::dict &d, bool execute) {
 // (BatchGEMMSeq::outer_perform) and returns the enlarged operators.
 template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
     typedef SparseMatrixInfo<S> Info;
+    static const bool dbg_clock = getenv("B2X_PLAN_DEBUG") != nullptr; // (development aid: phases of the walk on stderr)
+    const auto t_start = std::chrono::steady_clock::now();
+    auto t_last = t_start;
+    auto lap = [&](const char *what) {
+        if (!dbg_clock)
+            return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[b2x blocking] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t_last).count());
+        t_last = n;
+    };
     std::map<int, std::shared_ptr<Info>> cache;
     py::array_t<double> x = py::array_t<double>(py::array::ensure(d["x"]));
     py::array_t<double> site = py::array_t<double>(py::array::ensure(d["site"]));
@@ -446,27 +457,38 @@ template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
             exprs[i].push_back(t);
         }
     }
+    lap("infos + expressions");
     auto seq = std::make_shared<BatchGEMMSeq>();
     TensorFunctions<S> tfn(std::make_shared<OperatorFunctions<S>>(seq));
     tfn.contract(lop, rop, c, exprs);
-    std::vector<b2x_outer_term> t = seq->outer_terms;
+    lap("walk");
+    // the records go straight into the array that is returned (one pass over 64 bytes per term: a blocking list of 4e5 terms
+    // was copied three times through freshly mapped memory, which cost more than the walk itself)
+    const size_t nt = seq->outer_terms.size();
+    py::array_t<uint8_t> pa(nt * sizeof(b2x_outer_term));
+    b2x_outer_term *t = reinterpret_cast<b2x_outer_term *>(pa.mutable_data());
+    const double *x0 = x.data(), *x1 = x0 + x.size(), *s0 = site.data(), *s1 = s0 + site.size();
+    const double *m0 = tmpbuf.empty() ? nullptr : tmpbuf.data(), *m1 = tmpbuf.empty() ? nullptr : m0 + tmpbuf.size();
+    const uint64_t x_len = (uint64_t)x.size();
     auto classify = [&](const double *p, uint8_t &src, uint64_t &off) {
-        if (p >= x.data() && p < x.data() + x.size())
-            src = 1, off = (uint64_t)(p - x.data());
-        else if (p >= site.data() && p < site.data() + site.size())
-            src = 0, off = (uint64_t)(p - site.data());
-        else if (!tmpbuf.empty() && p >= tmpbuf.data() && p < tmpbuf.data() + tmpbuf.size())
-            src = 1, off = (uint64_t)x.size() + (uint64_t)(p - tmpbuf.data()); // temporaries: behind x in the input vector
+        if (p >= x0 && p < x1)
+            src = 1, off = (uint64_t)(p - x0);
+        else if (p >= s0 && p < s1)
+            src = 0, off = (uint64_t)(p - s0);
+        else if (m0 && p >= m0 && p < m1)
+            src = 1, off = x_len + (uint64_t)(p - m0); // temporaries: behind x in the input vector
         else
             throw std::runtime_error("symbolic_blocking: operand outside the fixture's data");
     };
-    for (size_t i = 0; i < t.size(); i++) {
+    const double *v0 = v.data();
+    lap("array");
+    for (size_t i = 0; i < nt; i++) {
+        t[i] = seq->outer_terms[i];
         classify(seq->oa_ptr[i], t[i].a_src, t[i].a_off);
         classify(seq->ob_ptr[i], t[i].b_src, t[i].b_off);
-        t[i].c_off = (uint64_t)(seq->oc_ptr[i] - v.data());
+        t[i].c_off = (uint64_t)(seq->oc_ptr[i] - v0);
     }
-    py::array_t<uint8_t> pa(t.size() * sizeof(b2x_outer_term));
-    std::memcpy(pa.mutable_data(), t.data(), t.size() * sizeof(b2x_outer_term));
+    lap("offsets + copy");
     if (tmpbuf.empty()) {
         if (execute)
             seq->outer_perform({{v.mutable_data(), (size_t)v.size()}});

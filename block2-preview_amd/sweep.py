@@ -133,6 +133,31 @@ def limit_host_blas():
     threadpool_limits(limits=n, user_api="blas")
 
 
+_heap_retained = False
+
+
+def retain_host_heap():
+    """The host walks of a site (blocking, rotation, H_eff) build lists of 1e5..1e6 records, tens of MB each, in memory that
+    glibc maps and unmaps per allocation above its mmap threshold — and a page fault costs microseconds in a virtualised
+    container: filling the 26 MB record array of a Cr2 M=250 blocking took 100 ms of page faults against 6 ms of copying
+    (B2X_PLAN_DEBUG=1 clocks, tools/outer_build_clock.py).  Once per process the thresholds are raised so that freed blocks stay
+    in the heap and are reused (mallopt: M_MMAP_THRESHOLD 1 GiB, M_TRIM_THRESHOLD 2 GiB, M_TOP_PAD 64 MiB); B2X_HOST_HEAP=0
+    leaves the allocator alone."""
+    global _heap_retained
+    if _heap_retained or os.environ.get("B2X_HOST_HEAP", "1") == "0":
+        return
+    _heap_retained = True
+    try:
+        import ctypes
+
+        libc = ctypes.CDLL(None)
+        libc.mallopt(-3, 1 << 30)        # M_MMAP_THRESHOLD
+        libc.mallopt(-1, (2 << 30) - 1)  # M_TRIM_THRESHOLD
+        libc.mallopt(-2, 64 << 20)       # M_TOP_PAD
+    except (OSError, AttributeError):
+        pass
+
+
 class OpTensor:
     """operator blocks of one (enlarged or rotated) block in HBM: one device vector + {operator key: (offset, length)}"""
 
@@ -154,6 +179,20 @@ def _info(d, i):
                             "ntot": d[pre + "ntot"].astype(np.int64), "dq": int(d[pre + "meta"][0]),
                             "len": int(d[pre + "meta"][3])}
     return v
+
+
+def _address_space(n):
+    """a host array a recording walk takes ADDRESSES from (operator blocks, psi): never read, never written, so not
+    initialised either (np.zeros would have to clear it once the heap is retained, retain_host_heap)"""
+    return np.empty(max(int(n), 1))[:int(n)]
+
+
+def _records(raw, dtype):
+    """the byte array a symbolic walk returns, seen as its records (no copy: a blocking list is tens of MB)"""
+    a = np.asarray(raw)
+    if a.dtype == np.uint8 and a.flags.c_contiguous and a.ctypes.data % 8 == 0:
+        return a.view(dtype)
+    return np.frombuffer(a.tobytes(), dtype)
 
 
 def _fields(q):
@@ -178,6 +217,7 @@ class DMRG:
         from . import b2x_host
 
         limit_host_blas()
+        retain_host_heap()
         self.fx, self.sym, self.host = fixture, sym, b2x_host
         self.conv_thrd, self.rng = conv_thrd, np.random.default_rng(seed)
         self.L, self.R = {}, {}          # rotated blocks by the site their enlarged successor starts from
@@ -248,10 +288,10 @@ class DMRG:
         lens = [(_info(d, i)["len"] if o >= 0 else 0) for i, o in zip(d[pre + ".info"], d[pre + ".off"])]
         x, tmp = self._repack(blk, d[pre + ".key"], d[pre + ".off"], lens, xl)
         dd = dict(d)
-        dd["x"] = np.zeros(xl)
+        dd["x"] = _address_space(xl)
         res = self.host.symbolic_blocking(self.sym, dd, False)
         terms, v = res[0], res[1]
-        terms = np.frombuffer(np.asarray(terms).tobytes(), OUTER_TERM_DTYPE)
+        terms = _records(terms, OUTER_TERM_DTYPE)
         layout = {int(k): (int(o), _info(d, i)["len"]) for k, i, o in zip(d["c.key"], d["c.info"], d["c.off"])}
         out = OpTensor(len(v), layout)
         site = capi.Arena.from_host([np.ascontiguousarray(d["site"], np.float64)])
@@ -259,7 +299,7 @@ class DMRG:
         if len(res) == 4:
             # operator sums with transposed members (sum-MPO MPOs): the temporaries live behind the block operators in the
             # input vector and are formed first, by a pass that reads and writes that extended vector
-            sum_terms = np.frombuffer(np.asarray(res[2]).tobytes(), OUTER_TERM_DTYPE)
+            sum_terms = _records(res[2], OUTER_TERM_DTYPE)
             x_len = xl + int(res[3])
             xe = OpTensor(x_len, {})
             if xl:
@@ -298,9 +338,9 @@ class DMRG:
         lens = [_info(d, i)["len"] for i in d["a.info"]]
         x, tmp = self._repack(enl, d["a.key"], d["a.off"], lens, xl)
         dd = dict(d)
-        dd["x"], dd["arena"] = np.zeros(xl), np.zeros(al)
+        dd["x"], dd["arena"] = _address_space(xl), _address_space(al)
         pairs, v = self.host.symbolic_rotate(self.sym, dd, False)
-        pairs = np.frombuffer(np.asarray(pairs).tobytes(), PAIR_DTYPE)
+        pairs = _records(pairs, PAIR_DTYPE)
         assert len(mps) == al
         arena = capi.Arena.from_host([np.ascontiguousarray(mps, np.float64)])
         plan = capi.Plan(arena, pairs, xl, vl)
@@ -329,7 +369,7 @@ class DMRG:
                 so, sl = rot.layout[k]
                 assert sl == l
                 capi.memcpy_d2d(out.buf.ptr + 8 * o, rot.buf.ptr + 8 * so, l)
-        terms = np.frombuffer(np.asarray(self.host.symbolic_transform(self.sym, d)).tobytes(), OUTER_TERM_DTYPE)
+        terms = _records(self.host.symbolic_transform(self.sym, d), OUTER_TERM_DTYPE)
         dummy = capi.Arena.from_host([np.zeros(1)])
         capi.outer_build(dummy, terms, out.buf.ptr, out.buf.ptr, True, total, total)
         capi.device_sync()
@@ -349,10 +389,10 @@ class DMRG:
         t0 = time.perf_counter()
         al = int(d["arena.len"][0])
         dd = dict(d)
-        dd["arena"] = np.zeros(al)
+        dd["arena"] = _address_space(al)
         h = self.host.SymbolicEffectiveHamiltonian(self.sym, dd)
         h.record()
-        pairs = np.frombuffer(np.asarray(h.pairs()).tobytes(), PAIR_DTYPE)
+        pairs = _records(h.pairs(), PAIR_DTYPE)
         dterms = np.asarray(h.diag_terms())
         kinfo = _info(d, d["ket.info"][0])
         n = kinfo["len"]
@@ -389,7 +429,7 @@ class DMRG:
         al, n = int(d["arena.len"][0]), part["n"]
         assert al == part["arena_t"].n, "the noise step of a site shares the operator arena of its effective Hamiltonian"
         dd = dict(d)
-        dd["arena"], dd["psi"] = np.zeros(al), np.zeros(n)
+        dd["arena"], dd["psi"] = _address_space(al), _address_space(n)
         h = self.host.SymbolicEffectiveHamiltonian(self.sym, dd)
         gb, _ = h.perturbative_noise(dd, False)
         gemms = np.frombuffer(bytes(gb), GEMM_DTYPE)
