@@ -24,7 +24,7 @@ DECLARED_SYMBOLS = [
     "b2x_plan_cache_stats", "b2x_plan_cache_clear", "b2x_trim",
     "b2x_gemm_plan_create", "b2x_outer_build",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
-    "b2x_vec_multi_dot", "b2x_vec_pair_dots", "b2x_vec_olsen_prepare_to", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
+    "b2x_vec_multi_dot", "b2x_vec_pair_dots", "b2x_vec_olsen_prepare_to", "b2x_vec_gather", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
     "b2x_comm_init", "b2x_comm_init_session", "b2x_comm_unique_id", "b2x_comm_init_id", "b2x_comm_rank", "b2x_allreduce_sum", "b2x_broadcast",
     "b2x_barrier", "b2x_comm_destroy",
 ]
@@ -253,6 +253,16 @@ def diag_build(arena, terms, diag, diag_len=None, on_device=False, stream=0):
 def memcpy_d2d(dst_ptr, src_ptr, n_elems):
     """device-to-device copy of n_elems doubles (default stream)"""
     check(lib().b2x_vec_copy(C.c_void_p(int(src_ptr)), C.c_void_p(int(dst_ptr)), C.c_size_t(n_elems), None))
+
+
+def gather_d2d(dst_ptr, src_ptr, dst_offs, src_offs, lens):
+    """dst[dst_offs[i] : + lens[i]] = src[src_offs[i] : + lens[i]] for all i in one launch (element offsets into two device
+    vectors; default stream; returns when done)"""
+    n = len(lens)
+    if n == 0:
+        return
+    do, so, ln = (np.ascontiguousarray(a, np.uint64) for a in (dst_offs, src_offs, lens))
+    check(lib().b2x_vec_gather(C.c_void_p(int(dst_ptr)), C.c_void_p(int(src_ptr)), C.c_size_t(n), _ptr(do), _ptr(so), _ptr(ln), None))
 
 
 def outer_build(arena, terms, vin, vout, on_device=False, in_len=None, out_len=None, stream=0):

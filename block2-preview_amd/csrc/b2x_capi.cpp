@@ -1254,6 +1254,39 @@ int b2x_vec_copy(const double *x, double *y, size_t n, void *stream) {
     HIPCHK(hipMemcpyAsync(y, x, n * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return B2X_OK;
 }
+int b2x_vec_gather(double *dst, const double *src, size_t n_ranges, const uint64_t *dst_off, const uint64_t *src_off,
+                   const uint64_t *len, void *stream) {
+    if (!n_ranges)
+        return B2X_OK;
+    if (!dst || !src || !dst_off || !src_off || !len)
+        return fail(B2X_ERR_INVALID, "b2x_vec_gather: null argument");
+    static const uint64_t kCopyPiece = 32768; // elements per workgroup
+    struct D {
+        uint64_t dst, src, len;
+    };
+    static thread_local std::vector<D> ds;
+    ds.clear();
+    for (size_t i = 0; i < n_ranges; i++)
+        for (uint64_t o = 0; o < len[i]; o += kCopyPiece)
+            ds.push_back(D{dst_off[i] + o, src_off[i] + o, std::min<uint64_t>(kCopyPiece, len[i] - o)});
+    if (ds.empty())
+        return B2X_OK;
+    if (ds.size() > 0x7FFFFFFFull)
+        return fail(B2X_ERR_INVALID, "b2x_vec_gather: too many pieces");
+    void *dd = nullptr;
+    if (cached_alloc(&dd, ds.size() * sizeof(D)) != hipSuccess)
+        return fail(B2X_ERR_NOMEM, "b2x_vec_gather: out of device memory");
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(dd, ds.data(), ds.size() * sizeof(D), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess)
+        e = launch_gather(dd, (uint32_t)ds.size(), dst, src, st);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(st); // (the table is host memory of this call and a parked device vector afterwards)
+    (void)cached_free(dd);
+    if (e != hipSuccess)
+        return fail(B2X_ERR_DEVICE, std::string("b2x_vec_gather: ") + hipGetErrorString(e));
+    return B2X_OK;
+}
 int b2x_vec_zero(double *x, size_t n, void *stream) {
     HIPCHK(hipMemsetAsync(x, 0, n * sizeof(double), (hipStream_t)stream));
     return B2X_OK;

@@ -30,6 +30,8 @@ hipError_t launch_scal(double a, double *x, size_t n, hipStream_t st);
 hipError_t launch_precond(double *q, const double *diag, double shift, size_t n, hipStream_t st);
 hipError_t launch_olsen(const double *q, double *q_out, double *t, const double *c, const double *diag, double ld, size_t n,
                         hipStream_t st);
+// descs: device array of n {dst offset, src offset, length} triples (uint64 each, elements)
+hipError_t launch_gather(const void *descs, uint32_t n, double *dst, const double *src, hipStream_t st);
 hipError_t launch_pairdot(const double *const *us, const double *const *vs, int np, size_t n, double *partial, double *out,
                           hipStream_t st);
 hipError_t launch_lincomb(const double *const *vs, const double *coef, int nv, double *y, size_t n, hipStream_t st);

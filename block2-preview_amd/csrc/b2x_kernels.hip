@@ -913,6 +913,20 @@ __global__ __launch_bounds__(256) void vec_multidot_k(VecPtrs vp, int nv, const 
     if (threadIdx.x == 0)
         partial[(size_t)j * gridDim.x + blockIdx.x] = sh[0];
 }
+// dst[d.dst + i] = src[d.src + i], i < d.len, for every descriptor: the operator blocks of an enlarged block gathered into
+// the arena of the next step in ONE launch (a site has ~1e3 of them; one hipMemcpyAsync each was 3 us of host time apiece).
+// One workgroup per descriptor; the host cuts long ranges into pieces of kCopyPiece elements.
+struct CopyDesc {
+    uint64_t dst, src, len;
+};
+__global__ __launch_bounds__(256) void vec_gather_k(const CopyDesc *__restrict__ ds, double *__restrict__ dst,
+                                                    const double *__restrict__ src) {
+    const CopyDesc d = ds[blockIdx.x];
+    double *o = dst + d.dst;
+    const double *s = src + d.src;
+    for (uint64_t i = threadIdx.x; i < d.len; i += 256)
+        o[i] = s[i];
+}
 // the same for independent pairs: partial[j * nblk + b] = share of <u_j, v_j> (one launch and one host round trip for all
 // the dot products of a Davidson step; pointers only: 2 KB of kernel arguments for 128 pairs)
 struct PairPtrs {
@@ -1093,6 +1107,10 @@ hipError_t launch_multidot(const double *const *vs, int nv, const double *x, siz
     return hipGetLastError();
 }
 
+hipError_t launch_gather(const void *descs, uint32_t n, double *dst, const double *src, hipStream_t st) {
+    hipLaunchKernelGGL(vec_gather_k, dim3(n), dim3(256), 0, st, (const CopyDesc *)descs, dst, src);
+    return hipGetLastError();
+}
 hipError_t launch_pairdot(const double *const *us, const double *const *vs, int np, size_t n, double *partial, double *out,
                           hipStream_t st) {
     PairPtrs pp;

@@ -268,6 +268,7 @@ class DMRG:
         if total == src.n and all(src.layout.get(k) == v for k, v in want.items()):
             return src, False
         out = OpTensor(total, want)
+        do, so_, ln = [], [], []
         for k, (o, l) in want.items():
             if k not in src.layout:  # allocated by the reference but never written (a symbol that is zero at this site)
                 self.n_zero_ops += 1
@@ -275,7 +276,8 @@ class DMRG:
                 continue
             so, sl = src.layout[k]
             assert sl == l, "operator %x: length %d here, %d expected" % (k, sl, l)
-            capi.memcpy_d2d(out.buf.ptr + 8 * o, src.buf.ptr + 8 * so, l)
+            do.append(o), so_.append(so), ln.append(l)
+        capi.gather_d2d(out.buf.ptr, src.buf.ptr, do, so_, ln)
         return out, True
 
     def _block(self, d, blk):
@@ -364,11 +366,13 @@ class DMRG:
         lens = [(_info(d, i)["len"] if o >= 0 else 0) for i, o in zip(d["t.info"], d["t.off"])]
         have = {int(k): (int(o), int(l)) for k, o, l in zip(d["t.key"], d["t.off"], lens) if o >= 0 and l > 0}
         out = OpTensor(total, have)  # zero-filled: the new operators start from zero
+        do, so_, ln = [], [], []
         for k, (o, l) in have.items():
             if k in rot.layout:
                 so, sl = rot.layout[k]
                 assert sl == l
-                capi.memcpy_d2d(out.buf.ptr + 8 * o, rot.buf.ptr + 8 * so, l)
+                do.append(o), so_.append(so), ln.append(l)
+        capi.gather_d2d(out.buf.ptr, rot.buf.ptr, do, so_, ln)
         terms = _records(self.host.symbolic_transform(self.sym, d), OUTER_TERM_DTYPE)
         dummy = capi.Arena.from_host([np.zeros(1)])
         capi.outer_build(dummy, terms, out.buf.ptr, out.buf.ptr, True, total, total)
@@ -400,15 +404,17 @@ class DMRG:
         t0 = time.perf_counter()
         arena_t = OpTensor(al, {})
         for pre, blk in (("lopt", self.EL), ("ropt", self.ER)):
-            for k, o, l in zip(d[pre + ".key"], d[pre + ".off"], d[pre + ".len"]):
+            do, so_, ln = [], [], []  # the operators of one enlarged block gathered into the arena in one launch
+            for k, o, l in zip(d[pre + ".key"].tolist(), d[pre + ".off"].tolist(), d[pre + ".len"].tolist()):
                 if o >= 0 and l > 0:
-                    if int(k) not in blk.layout:
+                    if k not in blk.layout:
                         self.n_zero_ops += 1
-                        self.zero_log.append((self.fx.pos - 1, int(k), int(l)))
+                        self.zero_log.append((self.fx.pos - 1, k, l))
                         continue
-                    so, sl = blk.layout[int(k)]
+                    so, sl = blk.layout[k]
                     assert sl == l
-                    capi.memcpy_d2d(arena_t.buf.ptr + 8 * int(o), blk.buf.ptr + 8 * so, int(l))
+                    do.append(o), so_.append(so), ln.append(l)
+            capi.gather_d2d(arena_t.buf.ptr, blk.buf.ptr, do, so_, ln)
         arena = capi.Arena.adopt_device(arena_t.buf.ptr, al, keep=arena_t)
         plan = capi.Plan(arena, pairs, n, n)
         assert plan.stats["fallback"] == 0

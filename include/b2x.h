@@ -267,6 +267,11 @@ int b2x_vec_precondition(double *q, const double *diag, double shift, size_t n, 
  * q += -(c.q)/(c.t) * t using b2x_vec_multi_dot + b2x_vec_axpy.) */
 int b2x_vec_olsen_prepare(double *q, double *t, const double *c, const double *diag, double ld, size_t n,
                           void *stream);
+/* dst[dst_off[i] + k] = src[src_off[i] + k], k < len[i], for i < n_ranges (offsets and lengths in elements; ranges must not
+ * overlap in dst): one launch instead of n_ranges copies — the operator blocks of the enlarged blocks gathered into the arena
+ * of an effective Hamiltonian.  Returns when the copy is done. */
+int b2x_vec_gather(double *dst, const double *src, size_t n_ranges, const uint64_t *dst_off, const uint64_t *src_off,
+                   const uint64_t *len, void *stream);
 /* the same with the scaled residual written to q_out and q left as it is (q_out == q: b2x_vec_olsen_prepare): lets the
  * Davidson step take |q|^2, c.q_out, c.t and the projections of q_out and t on the basis from ONE b2x_vec_pair_dots */
 int b2x_vec_olsen_prepare_to(const double *q, double *q_out, double *t, const double *c, const double *diag, double ld,
