@@ -83,8 +83,19 @@ def device_count():
     return n.value
 
 
+_device_ordinal = 0
+
+
 def device_init(ordinal=0):
+    """selects the device for the CALLING thread (hipSetDevice is per thread: a helper thread calls this with
+    current_device() before its first device call)"""
+    global _device_ordinal
     check(lib().b2x_device_init(C.c_int(ordinal)))
+    _device_ordinal = int(ordinal)
+
+
+def current_device():
+    return _device_ordinal
 
 
 def device_sync():

@@ -377,9 +377,15 @@ PYBIND11_MODULE(b2x_host, m) {
               for (auto x : ors)
                   o.push_back((double *)x);
               int ndav = 0;
-              std::vector<double> e = IterativeMatrixFunctions::harmonic_davidson(
-                  f, (const double *)diag_dev, vs, n, shift, davidson_type, ndav, iprint, para ? &dc : nullptr, conv_thrd,
-                  rel_conv_thrd, max_iter, soft_max_iter, deflation_min_size, deflation_max_size, o, proj_weights);
+              std::vector<double> e;
+              {
+                  // no Python object is touched from here to the end of the solve: other Python threads may run (the sweep loop
+                  // prepares the next site's plan on one while the device iterates, sweep.DMRG._prefetch_next)
+                  py::gil_scoped_release nogil;
+                  e = IterativeMatrixFunctions::harmonic_davidson(
+                      f, (const double *)diag_dev, vs, n, shift, davidson_type, ndav, iprint, para ? &dc : nullptr, conv_thrd,
+                      rel_conv_thrd, max_iter, soft_max_iter, deflation_min_size, deflation_max_size, o, proj_weights);
+              }
               if (many)
                   return py::make_tuple(e, ndav);
               return py::make_tuple(e[0], ndav);

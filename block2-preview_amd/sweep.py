@@ -237,6 +237,9 @@ class DMRG:
         self.use_previous = True         # False: every site starts from the low end of the diagonal (the round-2 behaviour)
         self.basis, self.mpsL, self.mpsR = {}, {}, {}
         self.carry, self._at = None, None
+        # the next site's effective Hamiltonian prepared on a helper thread while the device solves this site (_prefetch_next)
+        self.prefetch = os.environ.get("B2X_SWEEP_PREFETCH", "1") != "0"
+        self._pool, self._ahead, self.n_prefetched = None, {}, 0
         self.guess_log = {}              # (sweep, site) -> (how the starting vector was made: "previous" / "same" / "diagonal",
                                          #                   its overlap with the solution)
 
@@ -283,26 +286,22 @@ class DMRG:
     def _block(self, d, blk):
         """enlarged block = block (x) site: symbolic_blocking records the element-wise terms, the device executes them"""
         t0 = time.perf_counter()
+        ready = self._take_ready()
         right = bool(d["meta"][2])
         pre = "rop" if right else "lop"  # the block-operator side of tensor_product's (lop, rop)
         self._last_basis = self._site_basis(d, "lop" if right else "rop")
         xl = int(d["x.len"][0])
         lens = [(_info(d, i)["len"] if o >= 0 else 0) for i, o in zip(d[pre + ".info"], d[pre + ".off"])]
         x, tmp = self._repack(blk, d[pre + ".key"], d[pre + ".off"], lens, xl)
-        dd = dict(d)
-        dd["x"] = _address_space(xl)
-        res = self.host.symbolic_blocking(self.sym, dd, False)
-        terms, v = res[0], res[1]
-        terms = _records(terms, OUTER_TERM_DTYPE)
+        terms, vlen, sum_terms, tmp_len = ready if ready is not None else self._record_blocking(d)
         layout = {int(k): (int(o), _info(d, i)["len"]) for k, i, o in zip(d["c.key"], d["c.info"], d["c.off"])}
-        out = OpTensor(len(v), layout)
+        out = OpTensor(vlen, layout)
         site = capi.Arena.from_host([np.ascontiguousarray(d["site"], np.float64)])
         x_len = xl
-        if len(res) == 4:
+        if sum_terms is not None:
             # operator sums with transposed members (sum-MPO MPOs): the temporaries live behind the block operators in the
             # input vector and are formed first, by a pass that reads and writes that extended vector
-            sum_terms = _records(res[2], OUTER_TERM_DTYPE)
-            x_len = xl + int(res[3])
+            x_len = xl + tmp_len
             xe = OpTensor(x_len, {})
             if xl:
                 capi.memcpy_d2d(xe.buf.ptr, x.buf.ptr, xl)
@@ -310,7 +309,7 @@ class DMRG:
                 x.close()
             x, tmp = xe, True
             capi.outer_build(site, sum_terms, x.buf.ptr, x.buf.ptr, True, x_len, x_len)
-        capi.outer_build(site, terms, x.buf.ptr, out.buf.ptr, True, x_len, len(v))
+        capi.outer_build(site, terms, x.buf.ptr, out.buf.ptr, True, x_len, vlen)
         capi.device_sync()
         site.close()
         if tmp:
@@ -336,13 +335,12 @@ class DMRG:
     def _rotate(self, d, enl, mps):
         """rotated block = A^T . enlarged . A per operator sector: symbolic_rotate records the GEMM pairs"""
         t0 = time.perf_counter()
+        pairs = self._take_ready()
         xl, vl, al = int(d["meta"][5]), int(d["meta"][6]), int(d["meta"][7])
         lens = [_info(d, i)["len"] for i in d["a.info"]]
         x, tmp = self._repack(enl, d["a.key"], d["a.off"], lens, xl)
-        dd = dict(d)
-        dd["x"], dd["arena"] = _address_space(xl), _address_space(al)
-        pairs, v = self.host.symbolic_rotate(self.sym, dd, False)
-        pairs = _records(pairs, PAIR_DTYPE)
+        if pairs is None:
+            pairs = self._record_rotation(d)
         assert len(mps) == al
         arena = capi.Arena.from_host([np.ascontiguousarray(mps, np.float64)])
         plan = capi.Plan(arena, pairs, xl, vl)
@@ -392,12 +390,11 @@ class DMRG:
         device.  (sum-MPO: one such part per rank; the parts are solved together, _solve)"""
         t0 = time.perf_counter()
         al = int(d["arena.len"][0])
-        dd = dict(d)
-        dd["arena"] = _address_space(al)
-        h = self.host.SymbolicEffectiveHamiltonian(self.sym, dd)
-        h.record()
-        pairs = _records(h.pairs(), PAIR_DTYPE)
-        dterms = np.asarray(h.diag_terms())
+        ready = self._take_prefetched()
+        if ready is not None:
+            pairs, dterms = ready
+        else:
+            pairs, dterms = self._record_eff_ham(d)
         kinfo = _info(d, d["ket.info"][0])
         n = kinfo["len"]
         self.tm.add("eff_ham.record", t0)
@@ -423,6 +420,106 @@ class DMRG:
         self.tm.add("eff_ham.device", t0)
         return {"plan": plan, "arena": arena, "arena_t": arena_t, "diag": diag, "kinfo": kinfo, "n": n,
                 "const_e": float(d["const_e"][0]), "n_pairs": len(pairs)}
+
+    def _record_eff_ham(self, d):
+        """the symbolic walk of one effective Hamiltonian: (GEMM pairs, diagonal terms); needs no device and no operator data"""
+        dd = dict(d)
+        dd["arena"] = _address_space(int(d["arena.len"][0]))
+        h = self.host.SymbolicEffectiveHamiltonian(self.sym, dd)
+        h.record()
+        return _records(h.pairs(), PAIR_DTYPE), np.asarray(h.diag_terms())
+
+    # The host work of a site that depends on the STRUCTURE of the next site only — the walk of its effective Hamiltonian and
+    # the compilation of its H.psi plan, the largest single host cost of a site below M ~ 1000 — runs on a helper thread
+    # while the device iterates Davidson on the current site (davidson_device releases the GIL; ctypes calls do anyway).  The
+    # helper creates the plan over a scratch arena of the right extent and destroys it: the library parks a destroyed plan in
+    # its compiled-plan cache (b2x_plan_destroy), and the plan creation of the main thread takes it from there and only binds
+    # it to the real arena.  Nothing changes when the helper is late, fails or is switched off (B2X_SWEEP_PREFETCH=0): the
+    # main thread then walks and compiles itself, as before.
+    _PREFETCH_MAX_ARENA = 1 << 30  # elements (8 GB): above that the device time of a site dwarfs the compilation anyway
+
+    def _prefetch_next(self):
+        """queue the structure-only work of every step between here and the next effective Hamiltonian (inclusive): the
+        rotation's GEMM pairs + its plan (primed into the plan cache), the element-wise terms of the blockings, the walk +
+        plan of the effective Hamiltonian"""
+        if not self.prefetch:
+            return
+        fx = self.fx
+        todo = []
+        for k in range(fx.pos, len(fx.events)):
+            num, kind, fn = fx.events[k]
+            if kind in ("lblk", "rblk") and k + 1 < len(fx.events) and fx.events[k + 1][1] in ("lrot", "rrot"):
+                continue  # (the re-contraction block2 does before a rotation: the enlarged block is still in HBM here)
+            if kind in ("lrot", "rrot", "lblk", "rblk", "eham") and num not in self._ahead:
+                todo.append((num, kind, fn))
+            if kind == "eham":
+                break
+        if not todo:
+            return
+        if self._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="b2x-prefetch")
+        self._ahead = {n: f for n, f in self._ahead.items() if not f.done() or n >= todo[0][0]}  # (drop what was never taken)
+        for num, kind, fn in todo:
+            self._ahead[num] = self._pool.submit(self._prepare, num, kind, fn, capi.current_device())
+
+    def _prepare(self, num, kind, fn, ordinal):
+        try:
+            capi.device_init(ordinal)  # (the device is selected per thread)
+            d = self.fx._arrays(num, fn)
+            if kind == "eham":
+                al = int(d["arena.len"][0])
+                if al > self._PREFETCH_MAX_ARENA:
+                    return None
+                pairs, dterms = self._record_eff_ham(d)
+                n = _info(d, d["ket.info"][0])["len"]
+                tmp = capi.DeviceBuffer(al)
+                arena = capi.Arena.adopt_device(tmp.ptr, al, keep=tmp)
+                plan = capi.Plan(arena, pairs, n, n)
+                plan.close(), arena.close(), tmp.close()
+                return pairs, dterms
+            if kind in ("lrot", "rrot"):
+                xl, vl, al = int(d["meta"][5]), int(d["meta"][6]), int(d["meta"][7])
+                pairs = self._record_rotation(d)
+                arena = capi.Arena.from_host([np.zeros(al)])
+                plan = capi.Plan(arena, pairs, xl, vl)
+                plan.close(), arena.close()
+                return pairs
+            return self._record_blocking(d)
+        except Exception:  # the main thread does the work itself
+            return None
+
+    def _take_ready(self, num=None):
+        """what the helper prepared for the event the cursor just passed (or event `num`), or None"""
+        if num is None:
+            num = self.fx.events[self.fx.pos - 1][0]
+        fut = self._ahead.pop(num, None)
+        if fut is None:
+            return None
+        res = fut.result()
+        if res is not None:
+            self.n_prefetched += 1
+        return res
+
+    def _take_prefetched(self):
+        return self._take_ready(getattr(self, "_eham_num", None))
+
+    def _record_rotation(self, d):
+        dd = dict(d)
+        dd["x"], dd["arena"] = _address_space(int(d["meta"][5])), _address_space(int(d["meta"][7]))
+        pairs, _ = self.host.symbolic_rotate(self.sym, dd, False)
+        return _records(pairs, PAIR_DTYPE)
+
+    def _record_blocking(self, d):
+        """-> (terms, length of the enlarged block's vector, terms of the temporaries or None, length of their area)"""
+        dd = dict(d)
+        dd["x"] = _address_space(int(d["x.len"][0]))
+        res = self.host.symbolic_blocking(self.sym, dd, False)
+        terms, vlen = _records(res[0], OUTER_TERM_DTYPE), len(res[1])
+        if len(res) == 4:
+            return terms, vlen, _records(res[2], OUTER_TERM_DTYPE), int(res[3])
+        return terms, vlen, None, 0
 
     def _perturb(self, d, part, ket):
         """EffectiveHamiltonian::perturbative_noise (src/dmrg/effective_hamiltonian.hpp:252-423) on the device: the symbolic
@@ -478,6 +575,7 @@ class DMRG:
             guess, how = 1.0 / (dg - dg.min() + 0.1) ** 2 + 1e-3 * self.rng.standard_normal(n), "diagonal"
         ket = capi.DeviceBuffer(n, guess)
         ndav = 0
+        self._prefetch_next()
         for attempt in range(4):
             e, nd = self.host.davidson_device(plan._h.value, diag.ptr, ket.ptr, n, self.conv_thrd, 5000, more_plans=more)
             ndav += nd
@@ -889,6 +987,7 @@ class DMRG:
     def _eham_event(self, isw, i):
         _, d = self.fx.next("eham")
         assert (int(d["chain.meta"][0]), int(d["chain.meta"][1])) == (isw, i)
+        self._eham_num = self.fx.events[self.fx.pos - 1][0]
         return d
 
     def _finish_site(self, isw, i, e, ndav, psi, kinfo):
