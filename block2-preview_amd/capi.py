@@ -24,7 +24,7 @@ DECLARED_SYMBOLS = [
     "b2x_plan_cache_stats", "b2x_plan_cache_clear", "b2x_trim",
     "b2x_gemm_plan_create", "b2x_outer_build",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
-    "b2x_vec_multi_dot", "b2x_vec_pair_dots", "b2x_vec_olsen_prepare_to", "b2x_vec_gather", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
+    "b2x_vec_multi_dot", "b2x_vec_pair_dots", "b2x_vec_olsen_prepare_to", "b2x_vec_gather", "b2x_outer_plan_create", "b2x_outer_plan_execute", "b2x_outer_plan_destroy", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
     "b2x_comm_init", "b2x_comm_init_session", "b2x_comm_unique_id", "b2x_comm_init_id", "b2x_comm_rank", "b2x_allreduce_sum", "b2x_broadcast",
     "b2x_barrier", "b2x_comm_destroy",
 ]
@@ -285,6 +285,31 @@ def outer_build(arena, terms, vin, vout, on_device=False, in_len=None, out_len=N
         in_len, out_len = vin.size, vout.size
     check(lib().b2x_outer_build(arena._h, C.c_size_t(len(terms)), _ptr(terms), _ptr(vin), C.c_size_t(in_len),
                                 C.c_size_t(out_len), _ptr(vout), C.c_int(1 if on_device else 0), C.c_void_p(int(stream))))
+
+
+class OuterPlan:
+    """an element-wise term list compiled and uploaded once (b2x_outer_plan_create), executed on device vectors later"""
+
+    def __init__(self, terms, arena_len, in_len, out_len):
+        terms = np.ascontiguousarray(terms, OUTER_TERM_DTYPE)
+        self._h = C.c_void_p()
+        check(lib().b2x_outer_plan_create(C.byref(self._h), C.c_uint64(int(arena_len)), C.c_size_t(len(terms)), _ptr(terms),
+                                          C.c_size_t(int(in_len)), C.c_size_t(int(out_len))))
+
+    def execute(self, arena, in_ptr, out_ptr, stream=0):
+        check(lib().b2x_outer_plan_execute(self._h, arena._h, C.c_void_p(int(in_ptr)), C.c_void_p(int(out_ptr)),
+                                           C.c_void_p(int(stream))))
+
+    def close(self):
+        if self._h:
+            lib().b2x_outer_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def plan_cache_stats():

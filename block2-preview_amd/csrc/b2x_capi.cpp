@@ -1134,6 +1134,61 @@ int b2x_diag_build(const b2x_arena *arena, size_t n_terms, const b2x_diag_term *
     return rc;
 }
 
+// A term list compiled and uploaded once, executed later (and possibly on another thread's time: the sweep loop compiles the
+// blocking of the NEXT site while the device iterates Davidson).  b2x_outer_build is create + execute + destroy.
+struct b2x_outer_plan {
+    OWork *dw = nullptr;
+    OEntry *de = nullptr;
+    uint32_t n_work = 0;
+    uint64_t arena_len = 0;
+    size_t in_len = 0, out_len = 0;
+};
+int b2x_outer_plan_create(b2x_outer_plan **out, uint64_t arena_len, size_t n_terms, const b2x_outer_term *terms, size_t in_len,
+                          size_t out_len) {
+    if (!out || (n_terms && !terms))
+        return fail(B2X_ERR_INVALID, "b2x_outer_plan_create: null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(B2X_ERR_DEVICE, "b2x_outer_plan_create: no HIP device (this path has no CPU fallback)");
+    static thread_local std::vector<OWork> work; // (kept between calls: the lists of a blocking are tens of MB)
+    static thread_local std::vector<OEntry> entries;
+    std::string err;
+    int rc = compile_outer(n_terms, terms, in_len, out_len, arena_len, work, entries, err);
+    if (rc != B2X_OK)
+        return fail(rc, "b2x_outer_plan_create: " + err);
+    b2x_outer_plan *p = new b2x_outer_plan();
+    p->arena_len = arena_len, p->in_len = in_len, p->out_len = out_len, p->n_work = (uint32_t)work.size();
+    if (!work.empty()) {
+        rc = upload(&p->dw, work);
+        if (rc == B2X_OK)
+            rc = upload(&p->de, entries);
+        if (rc != B2X_OK) {
+            (void)cached_free(p->dw), (void)cached_free(p->de);
+            delete p;
+            return rc;
+        }
+    }
+    *out = p;
+    return B2X_OK;
+}
+int b2x_outer_plan_execute(const b2x_outer_plan *p, const b2x_arena *arena, const double *in_dev, double *out_dev, void *stream) {
+    if (!p || !arena || !out_dev || (p->in_len && !in_dev))
+        return fail(B2X_ERR_INVALID, "b2x_outer_plan_execute: null argument");
+    if (arena->len != p->arena_len)
+        return fail(B2X_ERR_INVALID, "b2x_outer_plan_execute: the arena is not of the extent the list was compiled for");
+    if (p->n_work == 0)
+        return B2X_OK;
+    HIPCHK(launch_outer(p->dw, p->n_work, p->de, arena->dev, in_dev, out_dev, 4, (hipStream_t)stream));
+    return B2X_OK;
+}
+int b2x_outer_plan_destroy(b2x_outer_plan *p) {
+    if (!p)
+        return B2X_OK;
+    (void)cached_free(p->dw), (void)cached_free(p->de); // (waits for the device: a running execute finishes first)
+    delete p;
+    return B2X_OK;
+}
+
 int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term *terms, const double *in, size_t in_len,
                     size_t out_len, double *out, int on_device, void *stream) {
     if (!arena || !out || (n_terms && !terms) || (in_len && !in))

@@ -293,7 +293,8 @@ class DMRG:
         xl = int(d["x.len"][0])
         lens = [(_info(d, i)["len"] if o >= 0 else 0) for i, o in zip(d[pre + ".info"], d[pre + ".off"])]
         x, tmp = self._repack(blk, d[pre + ".key"], d[pre + ".off"], lens, xl)
-        terms, vlen, sum_terms, tmp_len = ready if ready is not None else self._record_blocking(d)
+        terms, vlen, sum_terms, tmp_len = ready[:4] if ready is not None else self._record_blocking(d)
+        op = ready[4] if ready is not None else None
         layout = {int(k): (int(o), _info(d, i)["len"]) for k, i, o in zip(d["c.key"], d["c.info"], d["c.off"])}
         out = OpTensor(vlen, layout)
         site = capi.Arena.from_host([np.ascontiguousarray(d["site"], np.float64)])
@@ -309,8 +310,13 @@ class DMRG:
                 x.close()
             x, tmp = xe, True
             capi.outer_build(site, sum_terms, x.buf.ptr, x.buf.ptr, True, x_len, x_len)
-        capi.outer_build(site, terms, x.buf.ptr, out.buf.ptr, True, x_len, vlen)
+        if op is not None:
+            op.execute(site, x.buf.ptr, out.buf.ptr)
+        else:
+            capi.outer_build(site, terms, x.buf.ptr, out.buf.ptr, True, x_len, vlen)
         capi.device_sync()
+        if op is not None:
+            op.close()
         site.close()
         if tmp:
             x.close()
@@ -486,7 +492,10 @@ class DMRG:
                 plan = capi.Plan(arena, pairs, xl, vl)
                 plan.close(), arena.close()
                 return pairs
-            return self._record_blocking(d)
+            terms, vlen, sum_terms, tmp_len = self._record_blocking(d)
+            # the work list of the block products compiled and uploaded now (the site operators are the arena of this step)
+            op = capi.OuterPlan(terms, len(d["site"]), int(d["x.len"][0]) + tmp_len, vlen)
+            return terms, vlen, sum_terms, tmp_len, op
         except Exception:  # the main thread does the work itself
             return None
 

@@ -223,6 +223,15 @@ typedef struct b2x_outer_term {
     uint64_t a_off, b_off;
     uint64_t c_off;
 } b2x_outer_term;
+/* The same in two steps, for a list whose STRUCTURE is known before its data are (the blocking of the next site, compiled while
+ * the device is busy with this one): create compiles the list for an arena of `arena_len` elements and uploads the work list;
+ * execute launches out_dev += sum of terms on device vectors (asynchronous on `stream`); destroy waits for the device. */
+typedef struct b2x_outer_plan b2x_outer_plan;
+int b2x_outer_plan_create(b2x_outer_plan **out, uint64_t arena_len, size_t n_terms, const b2x_outer_term *terms, size_t in_len,
+                          size_t out_len);
+int b2x_outer_plan_execute(const b2x_outer_plan *plan, const b2x_arena *arena, const double *in_dev, double *out_dev,
+                           void *stream);
+int b2x_outer_plan_destroy(b2x_outer_plan *plan);
 /* out += sum of terms.  on_device != 0: in / out are device pointers.  Deterministic (no atomics). */
 int b2x_outer_build(const b2x_arena *arena, size_t n_terms, const b2x_outer_term *terms, const double *in, size_t in_len,
                     size_t out_len, double *out, int on_device, void *stream);

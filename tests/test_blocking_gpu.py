@@ -43,6 +43,32 @@ def test_random_terms_vs_oracle(gpu, seed):
     assert _close(out, ref)
 
 
+@pytest.mark.parametrize("seed", range(3))
+def test_two_step_outer_plan_equals_outer_build(gpu, seed):
+    """b2x_outer_plan_create / _execute / _destroy (a list compiled before its data exist, executed on device vectors later,
+    twice over different data) against the oracle and bitwise against the one-call form"""
+    rng = np.random.default_rng(160 + seed)
+    t, in_len, out_len, arena_len = random_outer_terms(rng, 500, max_dim=[9, 60, 250][seed])
+    op = gpu.OuterPlan(t, arena_len, in_len, out_len)
+    for rep in range(2):
+        arena, vin, out0 = rng.standard_normal(arena_len), rng.standard_normal(in_len), rng.standard_normal(out_len)
+        ref = out0.copy()
+        oracle.outer(t, arena, vin, ref)
+        ar = gpu.Arena.from_host([arena])
+        d_in, d_out = gpu.DeviceBuffer(in_len, vin), gpu.DeviceBuffer(out_len, out0)
+        op.execute(ar, d_in.ptr, d_out.ptr)
+        gpu.device_sync()
+        got = d_out.download()
+        one = out0.copy()
+        gpu.outer_build(ar, t, vin, one)
+        assert _close(got, ref) and got.tobytes() == one.tobytes()
+        wrong = gpu.Arena.from_host([np.zeros(arena_len + 1)])
+        with pytest.raises(gpu.B2XError):
+            op.execute(wrong, d_in.ptr, d_out.ptr)
+        wrong.close(), ar.close()
+    op.close()
+
+
 def test_host_mirror_outer_perform(gpu):
     """C++ host mirror: load the reference's terms, BatchGEMMSeq::outer_perform == reference result"""
     from block2_preview_amd import b2x_host

@@ -177,6 +177,30 @@ def test_davidson_starts_from_the_previous_site(gpu, chain, sym):
     assert "guess" in a.tm and a.tm["guess"] < a.tm["eigs"]
 
 
+def test_next_site_prepared_on_a_helper_thread(gpu, monkeypatch):
+    """the structure-only work of the next site (rotation pairs + plan, blocking terms, H_eff walk + plan) is done on a helper
+    thread during Davidson and picked up by event number; with the helper off the main thread does it — same energies, same
+    iteration counts either way"""
+    from block2_preview_amd import capi
+    from block2_preview_amd.sweep import DMRG, ChainFixture
+
+    runs = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("B2X_SWEEP_PREFETCH", on)
+        capi.plan_cache_clear()
+        fx = ChainFixture(os.path.join(GOLDEN, "chain_h10sz", "h10c"))
+        dm = DMRG(fx, "sz")
+        dm.init_environments()
+        dm.sweep(0, True), dm.sweep(1, False)
+        runs[on] = dm
+    a, b = runs["1"], runs["0"]
+    # per site after the first: one rotation, two blockings, one effective Hamiltonian (fewer at the ends of the chain)
+    assert a.n_prefetched >= 3 * 16 and b.n_prefetched == 0 and not b._ahead
+    assert a.ndav == b.ndav
+    assert max(abs(a.energies[k] - b.energies[k]) for k in a.energies) < 1e-12
+    assert capi.plan_cache_stats()[0] > 0  # the main thread's plan creations found the helper's plans
+
+
 def _ref_ndav(name):
     import json
 
