@@ -76,7 +76,9 @@ class ChainFixture:
 
     def _arrays(self, n, fn):
         mem = getattr(self, "_mem", None)
-        return dict(mem[n]) if mem is not None and n in mem else read_arrays(fn)
+        d = dict(mem[n]) if mem is not None and n in mem else read_arrays(fn)
+        d["_num"] = n  # (the event's number: what the loop's helper thread files its preparations under)
+        return d
 
     def next(self, *kinds):
         n, kind, fn = self.events[self.pos]
@@ -456,9 +458,11 @@ class DMRG:
             num, kind, fn = fx.events[k]
             if kind in ("lblk", "rblk") and k + 1 < len(fx.events) and fx.events[k + 1][1] in ("lrot", "rrot"):
                 continue  # (the re-contraction block2 does before a rotation: the enlarged block is still in HBM here)
-            if kind in ("lrot", "rrot", "lblk", "rblk", "eham") and num not in self._ahead:
+            if kind in ("lrot", "rrot", "lblk", "rblk", "eham", "enoise") and num not in self._ahead:
                 todo.append((num, kind, fn))
-            if kind == "eham":
+            if kind == "eham":  # (+ the perturbative-noise step of the same site, on a noisy sweep)
+                if k + 1 < len(fx.events) and fx.events[k + 1][1] == "enoise" and fx.events[k + 1][0] not in self._ahead:
+                    todo.append(fx.events[k + 1])
                 break
         if not todo:
             return
@@ -485,6 +489,16 @@ class DMRG:
                 plan = capi.Plan(arena, pairs, n, n)
                 plan.close(), arena.close(), tmp.close()
                 return pairs, dterms
+            if kind == "enoise":
+                al = int(d["arena.len"][0])
+                if al > self._PREFETCH_MAX_ARENA:
+                    return None
+                gemms, n, out_len = self._record_noise(d)
+                tmp = capi.DeviceBuffer(al)
+                arena = capi.Arena.adopt_device(tmp.ptr, al, keep=tmp)
+                gp = capi.GemmPlan(arena, gemms, n, out_len)
+                gp.close(), arena.close(), tmp.close()
+                return gemms
             if kind in ("lrot", "rrot"):
                 xl, vl, al = int(d["meta"][5]), int(d["meta"][6]), int(d["meta"][7])
                 pairs = self._record_rotation(d)
@@ -514,6 +528,17 @@ class DMRG:
     def _take_prefetched(self):
         return self._take_ready(getattr(self, "_eham_num", None))
 
+    def _record_noise(self, d):
+        """the single-GEMM list of the perturbative-noise step -> (records, psi length, length of the perturbed wavefunctions)"""
+        from .planfile import GEMM_DTYPE
+
+        al, n = int(d["arena.len"][0]), _info(d, d["ket.info"][0])["len"]
+        dd = dict(d)
+        dd["arena"], dd["psi"] = _address_space(al), _address_space(n)
+        h = self.host.SymbolicEffectiveHamiltonian(self.sym, dd)
+        gb, _ = h.perturbative_noise(dd, False)
+        return np.frombuffer(bytes(gb), GEMM_DTYPE), n, int(d["noise.args"][5])
+
     def _record_rotation(self, d):
         dd = dict(d)
         dd["x"], dd["arena"] = _address_space(int(d["meta"][5])), _address_space(int(d["meta"][7]))
@@ -535,17 +560,14 @@ class DMRG:
         walk records the single-GEMM list (host mirror, from the fixture's sub-labels and perturbed-ket infos), the list runs
         on the grouped-GEMM kernel over the SAME operator arena as H.psi (b2x_gemm_plan_create), the perturbed
         wavefunctions come back to the host for the density matrix.  d = the site's `enoise` event."""
-        from .planfile import GEMM_DTYPE
-
         t0 = time.perf_counter()
         al, n = int(d["arena.len"][0]), part["n"]
         assert al == part["arena_t"].n, "the noise step of a site shares the operator arena of its effective Hamiltonian"
-        dd = dict(d)
-        dd["arena"], dd["psi"] = _address_space(al), _address_space(n)
-        h = self.host.SymbolicEffectiveHamiltonian(self.sym, dd)
-        gb, _ = h.perturbative_noise(dd, False)
-        gemms = np.frombuffer(bytes(gb), GEMM_DTYPE)
         out_len = int(d["noise.args"][5])
+        gemms = self._take_ready(d.get("_num", -1))
+        if gemms is None:
+            gemms, n_, out_len = self._record_noise(d)
+            assert n_ == n
         self.tm.add("noise.record", t0)
         t0 = time.perf_counter()
         gp = capi.GemmPlan(part["arena"], gemms, n, out_len)
