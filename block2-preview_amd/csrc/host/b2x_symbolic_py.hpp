@@ -219,6 +219,7 @@ template <typename S> struct SymEH : SymEHBase {
         SparseMatrix<S> cmat, vmat;
         cmat.info = h->ket_info, vmat.info = h->bra_info;
         cmat.data = vmat.data = (double *)0;
+        py::gil_scoped_release nogil; // (the walk touches no Python object: other threads of the sweep loop may run)
         h->tf->tensor_product_multiply(h->expr, *h->lopt, *h->ropt, cmat, vmat, h->opdq);
     }
     void apply(py::array_t<double, py::array::c_style> b, py::array_t<double, py::array::c_style> c,
@@ -318,10 +319,13 @@ template <typename S> py::tuple sym_rotate(const py::dict &d, bool execute) {
     bra.factor = mf[0], ket.factor = mf[1];
     auto seq = std::make_shared<BatchGEMMSeq>();
     TensorFunctions<S> tf(std::make_shared<OperatorFunctions<S>>(seq));
-    if (right)
-        tf.right_rotate(a, bra, ket, c);
-    else
-        tf.left_rotate(a, bra, ket, c);
+    {
+        py::gil_scoped_release nogil; // (the walk touches no Python object)
+        if (right)
+            tf.right_rotate(a, bra, ket, c);
+        else
+            tf.left_rotate(a, bra, ket, c);
+    }
     std::vector<b2x_pair> p = seq->pairs;
     for (size_t i = 0; i < p.size(); i++) {
         p[i].x_off = (uint64_t)(((const double *)0 + p[i].x_off) - x.data());
@@ -460,7 +464,10 @@ template <typename S> py::tuple sym_blocking(const py::dict &d, bool execute) {
     lap("infos + expressions");
     auto seq = std::make_shared<BatchGEMMSeq>();
     TensorFunctions<S> tfn(std::make_shared<OperatorFunctions<S>>(seq));
-    tfn.contract(lop, rop, c, exprs);
+    {
+        py::gil_scoped_release nogil; // (the walk touches no Python object)
+        tfn.contract(lop, rop, c, exprs);
+    }
     lap("walk");
     // the records go straight into the array that is returned (one pass over 64 bytes per term: a blocking list of 4e5 terms
     // was copied three times through freshly mapped memory, which cost more than the walk itself)

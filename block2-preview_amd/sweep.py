@@ -469,7 +469,9 @@ class DMRG:
         if self._pool is None:
             from concurrent.futures import ThreadPoolExecutor
 
-            self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="b2x-prefetch")
+            # two helpers: the walks and the compilers run without the GIL, so the rotation + blockings of the next site and its
+            # effective Hamiltonian proceed side by side (each result is waited for by its own event number)
+            self._pool = ThreadPoolExecutor(max_workers=int(os.environ.get("B2X_SWEEP_HELPERS", "2")), thread_name_prefix="b2x-prefetch")
         self._ahead = {n: f for n, f in self._ahead.items() if not f.done() or n >= todo[0][0]}  # (drop what was never taken)
         for num, kind, fn in todo:
             self._ahead[num] = self._pool.submit(self._prepare, num, kind, fn, capi.current_device())
