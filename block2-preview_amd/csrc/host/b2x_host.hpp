@@ -770,10 +770,24 @@ inline bool operator&(DavidsonTypes a, DavidsonTypes b) { return ((uint16_t)a & 
 inline DavidsonTypes operator|(DavidsonTypes a, DavidsonTypes b) { return DavidsonTypes((uint16_t)a | (uint16_t)b); }
 
 // The PComm argument of the reference's davidson: rank / root and a broadcast of DEVICE vectors (b2x_broadcast, RCCL).
+// (bcast_fn / sum_fn: a transport supplied by the caller instead of the library's RCCL communicator — ranks that share one
+// card, which RCCL refuses, go through the host mirror's gloo transport in tests and rehearsals)
 struct DeviceComm {
     b2x_comm *comm = nullptr;
     int rank = 0, size = 1, root = 0;
-    void broadcast(double *dev, size_t n) const { check(b2x_broadcast(comm, dev, n, root, nullptr)); }
+    std::function<void(double *, size_t)> bcast_fn, sum_fn;
+    void broadcast(double *dev, size_t n) const {
+        if (bcast_fn)
+            bcast_fn(dev, n);
+        else
+            check(b2x_broadcast(comm, dev, n, root, nullptr));
+    }
+    void allreduce_sum(double *dev, size_t n) const {
+        if (sum_fn)
+            sum_fn(dev, n);
+        else
+            check(b2x_allreduce_sum(comm, dev, n, nullptr));
+    }
 };
 
 struct IterativeMatrixFunctions {

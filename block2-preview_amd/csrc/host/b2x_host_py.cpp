@@ -353,10 +353,22 @@ PYBIND11_MODULE(b2x_host, m) {
               b2x_plan *p = (b2x_plan *)plan;
               DeviceComm dc;
               const bool para = !comm.is_none();
-              if (para) {
+              if (para && py::isinstance<py::tuple>(comm)) { // (b2x_comm handle, rank, size, root): RCCL through the C ABI
                   py::tuple t = comm.cast<py::tuple>();
                   dc.comm = (b2x_comm *)t[0].cast<uintptr_t>();
                   dc.rank = t[1].cast<int>(), dc.size = t[2].cast<int>(), dc.root = t[3].cast<int>();
+              } else if (para) { // an object with rank / size / root, allreduce_device(ptr, n), broadcast_device(ptr, n, owner)
+                  dc.rank = comm.attr("rank").cast<int>(), dc.size = comm.attr("size").cast<int>();
+                  dc.root = comm.attr("root").cast<int>();
+                  const int root = dc.root;
+                  dc.sum_fn = [comm](double *p_, size_t n_) {
+                      py::gil_scoped_acquire gil; // (the solve runs without the GIL)
+                      comm.attr("allreduce_device")((uintptr_t)p_, n_);
+                  };
+                  dc.bcast_fn = [comm, root](double *p_, size_t n_) {
+                      py::gil_scoped_acquire gil;
+                      comm.attr("broadcast_device")((uintptr_t)p_, n_, root);
+                  };
               }
               size_t slen = n;
               auto f = [p, para, dc, slen, more_plans](const double *b, double *s) {
@@ -364,7 +376,7 @@ PYBIND11_MODULE(b2x_host, m) {
                   for (uintptr_t q : more_plans) // H = sum of several plans (sum-MPO ranks held by one process)
                       check(b2x_plan_execute((b2x_plan *)q, b, s, 1.0, 1, nullptr));
                   if (para) // ParallelTensorFunctions::operator() (parallel_tensor_functions.hpp:51-55)
-                      check(b2x_allreduce_sum(dc.comm, s, slen, nullptr));
+                      dc.allreduce_sum(s, slen);
               };
               const bool many = py::isinstance<py::sequence>(ket_dev);
               std::vector<double *> vs;
@@ -378,12 +390,14 @@ PYBIND11_MODULE(b2x_host, m) {
                   o.push_back((double *)x);
               int ndav = 0;
               std::vector<double> e;
+              const std::function<void(const double *, double *)> fop = f; // (made and destroyed with the GIL held: it may own Python references)
               {
-                  // no Python object is touched from here to the end of the solve: other Python threads may run (the sweep loop
-                  // prepares the next site's plan on one while the device iterates, sweep.DMRG._prefetch_next)
+                  // no Python object is touched from here to the end of the solve (a caller-supplied transport takes the GIL for
+                  // its own calls): other Python threads may run — the sweep loop prepares the next site on them while the device
+                  // iterates, sweep.DMRG._prefetch_next
                   py::gil_scoped_release nogil;
                   e = IterativeMatrixFunctions::harmonic_davidson(
-                      f, (const double *)diag_dev, vs, n, shift, davidson_type, ndav, iprint, para ? &dc : nullptr, conv_thrd,
+                      fop, (const double *)diag_dev, vs, n, shift, davidson_type, ndav, iprint, para ? &dc : nullptr, conv_thrd,
                       rel_conv_thrd, max_iter, soft_max_iter, deflation_min_size, deflation_max_size, o, proj_weights);
               }
               if (many)

@@ -78,6 +78,30 @@ class ParallelCommunicator:
         self.tcomm += time.perf_counter() - t
         return data
 
+    # collectives on DEVICE vectors whatever the transport: RCCL moves them where they are; gloo (ranks that share one card,
+    # which RCCL refuses: rehearsals and tests) bounces them through a host array
+    def allreduce_device(self, dev_ptr, n, stream=0):
+        if self._rccl is not None:
+            return self.allreduce_sum(dev_ptr, n, stream)
+        from . import capi
+
+        host = np.empty(int(n))
+        capi.check(capi.lib().b2x_memcpy_d2h(capi._ptr(host), capi.C.c_void_p(int(dev_ptr)), capi.C.c_size_t(int(n) * 8)))
+        self.allreduce_sum(host)
+        capi.check(capi.lib().b2x_memcpy_h2d(capi.C.c_void_p(int(dev_ptr)), capi._ptr(host), capi.C.c_size_t(int(n) * 8)))
+
+    def broadcast_device(self, dev_ptr, n, owner, stream=0):
+        if self._rccl is not None:
+            return self.broadcast(dev_ptr, owner, n, stream)
+        from . import capi
+
+        host = np.empty(int(n))
+        if self.rank == owner:
+            capi.check(capi.lib().b2x_memcpy_d2h(capi._ptr(host), capi.C.c_void_p(int(dev_ptr)), capi.C.c_size_t(int(n) * 8)))
+        self.broadcast(host, owner)
+        if self.rank != owner:
+            capi.check(capi.lib().b2x_memcpy_h2d(capi.C.c_void_p(int(dev_ptr)), capi._ptr(host), capi.C.c_size_t(int(n) * 8)))
+
     def barrier(self):
         self._need_peers()
         if self._rccl is not None:

@@ -237,6 +237,11 @@ class DMRG:
         # the state carried from site to site (block2: MPS::tensors / MPSInfo): the MPS tensors on both sides of the centre,
         # the site bases, and the wavefunction half of the last split — what the next site's Davidson starts from (_guess)
         self.use_previous = True         # False: every site starts from the low end of the diagonal (the round-2 behaviour)
+        # sum-MPO with one rank per PROCESS: a parallel.ParallelCommunicator (RCCL, or gloo for ranks that share a card).  This
+        # engine then carries ITS rank's event chain: sigma, the diagonal and the perturbed wavefunctions are summed over the
+        # ranks (ParallelTensorFunctions::operator(), parallel_tensor_functions.hpp:51-55; effective_hamiltonian.hpp:399-400),
+        # every rank runs the same Davidson and the same split on the same numbers
+        self.comm = None
         self.basis, self.mpsL, self.mpsR = {}, {}, {}
         self.carry, self._at = None, None
         # the next site's effective Hamiltonian prepared on a helper thread while the device solves this site (_prefetch_next)
@@ -576,6 +581,8 @@ class DMRG:
         out = capi.DeviceBuffer(out_len)
         gp.execute_device(ket.ptr, out.ptr, 1.0)
         capi.device_sync()
+        if self.comm is not None and self.comm.size > 1:  # comm->reduce_sum(perturb_ket, root): here every rank keeps the sum
+            self.comm.allreduce_device(out.ptr, out_len)
         pk = out.download()
         gp.close(), out.close()
         infos = [_info(d, i) for i in d["noise.vinfo"]]
@@ -596,6 +603,9 @@ class DMRG:
             assert q["n"] == n
             capi.check(capi.lib().b2x_vec_axpy(C.c_double(1.0), C.c_void_p(q["diag"].ptr), C.c_void_p(diag.ptr), C.c_size_t(n), None))
         more = [q["plan"]._h.value for q in parts[1:]]
+        comm = self.comm if self.comm is not None and self.comm.size > 1 else None
+        if comm is not None:
+            comm.allreduce_device(diag.ptr, n)  # (the diagonal of H = sum_r H_r)
         # Initial guess.  block2 starts Davidson from the wavefunction of the previous site moved to this one
         # (MovingEnvironment::propagate_wfn + contract_two_dot); so does this loop (_guess).  Where there is no previous
         # wavefunction (the first site of a calculation) it starts from the low end of the diagonal, the usual Davidson
@@ -610,7 +620,8 @@ class DMRG:
         ndav = 0
         self._prefetch_next()
         for attempt in range(4):
-            e, nd = self.host.davidson_device(plan._h.value, diag.ptr, ket.ptr, n, self.conv_thrd, 5000, more_plans=more)
+            e, nd = self.host.davidson_device(plan._h.value, diag.ptr, ket.ptr, n, self.conv_thrd, 5000, more_plans=more,
+                                              comm=self._davidson_comm(comm))
             ndav += nd
             if e <= dg.min() + 1e-9:
                 break
@@ -653,6 +664,16 @@ class DMRG:
             q["plan"].close(), q["arena"].close(), q["arena_t"].close(), q["diag"].close()
         ket.close()
         return e + const_e, ndav, psi, p0["kinfo"], sum(q["n_pairs"] for q in parts)
+
+    @staticmethod
+    def _davidson_comm(comm):
+        """what davidson_device takes: the C ABI's RCCL communicator as (handle, rank, size, root), any other transport as the
+        communicator object itself (its allreduce_device / broadcast_device are called back)"""
+        if comm is None:
+            return None
+        if getattr(comm, "_rccl", None) is not None:
+            return (comm._rccl._h.value, comm.rank, comm.size, comm.root)
+        return comm
 
     def _eigs(self, d, noise_event=None):
         return self._solve([self._eff_ham(d)], noise_event)

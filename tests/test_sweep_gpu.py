@@ -269,6 +269,43 @@ def test_sum_mpo_noisy_schedule_two_ranks(gpu):
     assert abs(dm.energies[(0, 3)] - one) < 1e-9
 
 
+@pytest.mark.parametrize("chain,n_sweeps,n_sites", [(("chain_n2su2_ij", "n2p.r%dof2"), 2, 18),
+                                                    (("chain_n2su2_ij_noisy", "n2pn.r%dof2"), 3, 27)])
+def test_sum_mpo_sweep_one_rank_per_process(gpu, tmp_path, chain, n_sweeps, n_sites):
+    """the sum-MPO calculation with ONE PROCESS PER RANK, as it runs on one GPU per rank: two processes, each replaying its
+    own rank's event chain of the reference's `mpirun -n 2` run with sweep.DMRG and a communicator; sigma is all-reduced inside
+    Davidson's H.psi (ParallelTensorFunctions::operator(), parallel_tensor_functions.hpp:51-55), the diagonal and the perturbed
+    wavefunctions are summed likewise, the new basis vectors are broadcast from the root.  (The two ranks share card 0 here,
+    which RCCL refuses: the transport is gloo through the host, the calls are the ones RCCL would carry.)  Both ranks must
+    report the reference's site energies, identical to each other bit for bit."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prefix = os.path.join(GOLDEN, *chain)
+    out = str(tmp_path / "res")
+    port = str(29000 + os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "sum_mpo_sweep_worker.py"), str(r), "2", port, prefix, "su2",
+                               str(n_sweeps), out], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=root)
+             for r in range(2)]
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-3000:]
+    res = [json.load(open(out + ".r%d" % r)) for r in range(2)]
+    from block2_preview_amd.sweep import ChainFixture
+
+    ref = ChainFixture(prefix % 0).ref_energy
+    assert len(ref) == n_sites
+    for r in res:
+        worst = max(abs(r["energies"]["%d,%d" % k] - e) for k, e in ref.items())
+        assert worst < 1e-7, (r["rank"], worst)
+        assert "previous" in r["starts"] and r["tcomm"] > 0
+    assert res[0]["energies"] == res[1]["energies"] and res[0]["ndav"] == res[1]["ndav"]
+    assert abs(min(res[0]["energies"].values()) - (-107.654122447525)) < 1e-7
+
+
 def _truncation_evidence(dm, fx):
     """what the truncation log of a replayed chain must show for the replay to count as the reference's calculation:
     (i) this loop's OWN choice of kept states (all eigenvalues of all sectors sorted, the largest k kept) gives the reference's
