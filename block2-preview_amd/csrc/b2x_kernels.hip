@@ -636,8 +636,12 @@ __device__ __forceinline__ void gg_body(const GItem &item, const GItem *item_ptr
 // is one or two chunks long and the exposed load latency, not the MFMA pipe, sets the pace) get an instantiation of
 // their own with half the registers (<= 128: no spills up to three row fragments) and 3/8 of the LDS: four waves per
 // SIMD instead of two hide that latency.
+#ifndef B2X_NARROW_WAVES
+#define B2X_NARROW_WAVES 4
+#endif
+static constexpr int kNarrowWaves = B2X_NARROW_WAVES; // waves per SIMD the 1-wave workgroups of the smallest tiles are compiled for
 template <int CF, int NW, int KC, bool SB, int TMAX>
-__global__ __launch_bounds__(NW * 64, TMAX <= 3 ? 4 : (TMAX <= 5 ? 3 : 2)) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
+__global__ __launch_bounds__(NW * 64, (NW == 1 && TMAX <= 2) ? kNarrowWaves : (TMAX <= 3 ? 4 : (TMAX <= 5 ? 3 : 2))) void gg_kernel(const GSeg *__restrict__ segs, const GItem *__restrict__ items,
                                                          const double *__restrict__ arena,
                                                          const double *__restrict__ psi, double *__restrict__ scratch,
                                                          double *__restrict__ slabs) {
