@@ -135,6 +135,22 @@ def limit_host_blas():
     threadpool_limits(limits=n, user_api="blas")
 
 
+_pool_shared = None
+
+
+def _helper_pool():
+    """the helper threads of the sweep loops of this process (DMRG._prefetch_next).  Two: the walks and the compilers run
+    without the GIL, so the rotation + blockings of the next site and its effective Hamiltonian proceed side by side (each
+    result is waited for by its own event number).  B2X_SWEEP_HELPERS sets the number."""
+    global _pool_shared
+    if _pool_shared is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        _pool_shared = ThreadPoolExecutor(max_workers=max(1, int(os.environ.get("B2X_SWEEP_HELPERS", "2"))),
+                                          thread_name_prefix="b2x-prefetch")
+    return _pool_shared
+
+
 _heap_retained = False
 
 
@@ -246,7 +262,7 @@ class DMRG:
         self.carry, self._at = None, None
         # the next site's effective Hamiltonian prepared on a helper thread while the device solves this site (_prefetch_next)
         self.prefetch = os.environ.get("B2X_SWEEP_PREFETCH", "1") != "0"
-        self._pool, self._ahead, self.n_prefetched = None, {}, 0
+        self._pool, self._ahead, self.n_prefetched, self.prefetch_errors = None, {}, 0, []
         self.guess_log = {}              # (sweep, site) -> (how the starting vector was made: "previous" / "same" / "diagonal",
                                          #                   its overlap with the solution)
 
@@ -472,11 +488,7 @@ class DMRG:
         if not todo:
             return
         if self._pool is None:
-            from concurrent.futures import ThreadPoolExecutor
-
-            # two helpers: the walks and the compilers run without the GIL, so the rotation + blockings of the next site and its
-            # effective Hamiltonian proceed side by side (each result is waited for by its own event number)
-            self._pool = ThreadPoolExecutor(max_workers=int(os.environ.get("B2X_SWEEP_HELPERS", "2")), thread_name_prefix="b2x-prefetch")
+            self._pool = _helper_pool()
         self._ahead = {n: f for n, f in self._ahead.items() if not f.done() or n >= todo[0][0]}  # (drop what was never taken)
         for num, kind, fn in todo:
             self._ahead[num] = self._pool.submit(self._prepare, num, kind, fn, capi.current_device())
@@ -517,7 +529,8 @@ class DMRG:
             # the work list of the block products compiled and uploaded now (the site operators are the arena of this step)
             op = capi.OuterPlan(terms, len(d["site"]), int(d["x.len"][0]) + tmp_len, vlen)
             return terms, vlen, sum_terms, tmp_len, op
-        except Exception:  # the main thread does the work itself
+        except Exception as e:  # the main thread does the work itself (and reports its own error, if it has one too)
+            self.prefetch_errors.append((num, kind, repr(e)))
             return None
 
     def _take_ready(self, num=None):

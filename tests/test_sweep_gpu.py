@@ -196,6 +196,7 @@ def test_next_site_prepared_on_a_helper_thread(gpu, monkeypatch):
     a, b = runs["1"], runs["0"]
     # per site after the first: one rotation, two blockings, one effective Hamiltonian (fewer at the ends of the chain)
     assert a.n_prefetched >= 3 * 16 and b.n_prefetched == 0 and not b._ahead
+    assert a.prefetch_errors == []
     assert a.ndav == b.ndav
     assert max(abs(a.energies[k] - b.energies[k]) for k in a.energies) < 1e-12
     assert capi.plan_cache_stats()[0] > 0  # the main thread's plan creations found the helper's plans
