@@ -10,6 +10,14 @@ environment to the last site:
     H_eff      (EffectiveHamiltonian ctor: plan + diagonal)           -> b2x_plan_create, b2x_diag_build
     eigs       (IterativeMatrixFunctions::davidson)                   -> device-resident Davidson over b2x_plan_execute
     split      (density matrix of psi, eigenvectors = new MPS tensor) -> host (numpy; a few small symmetric eigenproblems)
+    next guess (MovingEnvironment::propagate_wfn, contract_two_dot)   -> host: the wavefunction half of the split regrouped
+                                                                         to the next site's fused index (Racah recoupling
+                                                                         for SU2) x the neighbouring MPS tensor (_guess)
+
+While the device iterates Davidson on one site, helper threads prepare what the NEXT site needs and what depends on its
+structure only: the rotation's GEMM pairs and plan, the blocking terms and their compiled work lists, the walk and the plan of
+its effective Hamiltonian, its noise list (_prefetch_next).  Sum-MPO runs either with all ranks in one process (SumMPODMRG) or
+with one process per rank and a communicator (DMRG.comm).
 
 The SYMBOLIC side of every step — operator infos, quantum-number bookkeeping, the expressions of the enlarged operators
 and of H_eff — belongs to block2's MPO / Partition layers, which are out of scope: it is taken as data from
