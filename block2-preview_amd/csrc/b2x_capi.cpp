@@ -1293,6 +1293,36 @@ int b2x_vec_pair_dots(const double *const *us, const double *const *vs, int n_pa
     memcpy(host_result, g_dot_host, n_pairs * sizeof(double));
     return B2X_OK;
 }
+// out = (v - sum_j <b_j, v> b_j) / |.|, everything on the device and asynchronous on `stream`; *status (pinned host memory owned by
+// the library, see b2x_vec_gs_status) becomes 1 when the norm was not safely positive.
+static int *g_gs_flag_dev = nullptr, *g_gs_flag_host = nullptr;
+int b2x_vec_gs_finish(const double *const *bs, int m, const double *v, double *out, size_t n, void *stream) {
+    if (m < 0 || m > 63 || (m && !bs) || !v || !out)
+        return fail(B2X_ERR_INVALID, "b2x_vec_gs_finish: need 0 <= m <= 63");
+    int rc = dot_scratch();
+    if (rc != B2X_OK)
+        return rc;
+    if (!g_gs_flag_dev) {
+        HIPCHK(hipMalloc((void **)&g_gs_flag_dev, sizeof(int)));
+        HIPCHK(hipMemset(g_gs_flag_dev, 0, sizeof(int)));
+        HIPCHK(hipHostMalloc((void **)&g_gs_flag_host, sizeof(int), hipHostMallocDefault));
+        *g_gs_flag_host = 0;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(launch_gs_finish(bs, m, v, g_dot_partial, g_dot_out, out, n, g_gs_flag_dev, st));
+    HIPCHK(hipMemcpyAsync(g_gs_flag_host, g_gs_flag_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    return B2X_OK;
+}
+int b2x_vec_gs_status(int *degenerate, int reset) {
+    if (!degenerate)
+        return fail(B2X_ERR_INVALID, "b2x_vec_gs_status: null argument");
+    *degenerate = g_gs_flag_host ? *g_gs_flag_host : 0;
+    if (reset && g_gs_flag_dev && *degenerate) {
+        HIPCHK(hipMemset(g_gs_flag_dev, 0, sizeof(int)));
+        *g_gs_flag_host = 0;
+    }
+    return B2X_OK;
+}
 int b2x_vec_dot(const double *x, const double *y, size_t n, double *host_result, void *stream) {
     const double *vs[1] = {x};
     return b2x_vec_multi_dot(vs, 1, y, n, host_result, stream);

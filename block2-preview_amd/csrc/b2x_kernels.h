@@ -30,6 +30,9 @@ hipError_t launch_scal(double a, double *x, size_t n, hipStream_t st);
 hipError_t launch_precond(double *q, const double *diag, double shift, size_t n, hipStream_t st);
 hipError_t launch_olsen(const double *q, double *q_out, double *t, const double *c, const double *diag, double ld, size_t n,
                         hipStream_t st);
+// second Gram-Schmidt pass + normalisation without a host round trip (m <= 63): dots / partial = device scratch of the dot products
+hipError_t launch_gs_finish(const double *const *bs, int m, const double *v, double *partial, double *dots, double *out, size_t n,
+                            int *flag, hipStream_t st);
 // descs: device array of n {dst offset, src offset, length} triples (uint64 each, elements)
 hipError_t launch_gather(const void *descs, uint32_t n, double *dst, const double *src, hipStream_t st);
 hipError_t launch_pairdot(const double *const *us, const double *const *vs, int np, size_t n, double *partial, double *out,

@@ -917,6 +917,26 @@ __global__ __launch_bounds__(256) void vec_multidot_k(VecPtrs vp, int nv, const 
     if (threadIdx.x == 0)
         partial[(size_t)j * gridDim.x + blockIdx.x] = sh[0];
 }
+// Second Gram-Schmidt pass + normalisation with the coefficients still ON THE DEVICE (dots[j] = <b_j, v>, dots[m] = <v, v>, as
+// vec_pairdot_k + vec_multidot_final_k left them): out = (v - sum_j dots[j] b_j) / sqrt(<v, v> - sum_j dots[j]^2).  The norm of
+// the result follows from the dots for an orthonormal basis; when it is not safely positive (the new direction lies in the span of
+// the basis to rounding) the unnormalised difference is written and *flag set: the host looks at the flag after its next wait.
+__global__ void vec_gs_finish_k(VecPtrs vp, int m, const double *__restrict__ v, const double *__restrict__ dots,
+                                double *__restrict__ out, size_t n, int *flag) {
+    double nrm2 = dots[m];
+    for (int j = 0; j < m; j++)
+        nrm2 -= dots[j] * dots[j];
+    const bool ok = nrm2 > 1e-24 * fabs(dots[m]) && nrm2 > 0.0;
+    const double inv = ok ? 1.0 / sqrt(nrm2) : 1.0;
+    if (!ok && blockIdx.x == 0 && threadIdx.x == 0)
+        *flag = 1;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double s = v[i];
+        for (int j = 0; j < m; j++)
+            s -= dots[j] * vp.p[j][i];
+        out[i] = s * inv;
+    }
+}
 // dst[d.dst + i] = src[d.src + i], i < d.len, for every descriptor: the operator blocks of an enlarged block gathered into
 // the arena of the next step in ONE launch (a site has ~1e3 of them; one hipMemcpyAsync each was 3 us of host time apiece).
 // One workgroup per descriptor; the host cuts long ranges into pieces of kCopyPiece elements.
@@ -1111,6 +1131,19 @@ hipError_t launch_multidot(const double *const *vs, int nv, const double *x, siz
     return hipGetLastError();
 }
 
+hipError_t launch_gs_finish(const double *const *bs, int m, const double *v, double *partial, double *dots, double *out, size_t n,
+                            int *flag, hipStream_t st) {
+    PairPtrs pp;
+    VecPtrs vp;
+    for (int j = 0; j < m; j++)
+        pp.u[j] = bs[j], pp.v[j] = v, vp.p[j] = bs[j], vp.coef[j] = 0.0;
+    pp.u[m] = v, pp.v[m] = v;
+    int nb = multidot_blocks(n);
+    hipLaunchKernelGGL(vec_pairdot_k, dim3(nb, m + 1), dim3(256), 0, st, pp, n, partial);
+    hipLaunchKernelGGL(vec_multidot_final_k, dim3(m + 1), dim3(256), 0, st, partial, nb, dots);
+    hipLaunchKernelGGL(vec_gs_finish_k, dim3(vec_grid(n)), dim3(256), 0, st, vp, m, v, dots, out, n, flag);
+    return hipGetLastError();
+}
 hipError_t launch_gather(const void *descs, uint32_t n, double *dst, const double *src, hipStream_t st) {
     hipLaunchKernelGGL(vec_gather_k, dim3(n), dim3(256), 0, st, (const CopyDesc *)descs, dst, src);
     return hipGetLastError();

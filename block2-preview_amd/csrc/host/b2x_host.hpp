@@ -941,6 +941,11 @@ struct IterativeMatrixFunctions {
                               !(davidson_type & DavidsonTypes::NoPrecond) && !(fused_env && fused_env[0] == '0');
         std::vector<const double *> fu, fv; // pairs of the fused dot products, and their results
         std::vector<double> fr;
+        int gs_pending = -1; // basis vector whose device-side normalisation has not been confirmed yet
+        if (fused_ok) {      // (a flag left by an earlier solve that ended before looking at it)
+            int stale = 0;
+            check(b2x_vec_gs_status(&stale, 1));
+        }
         double t_op = 0, t_eig = 0;
         auto now = []() { return std::chrono::steady_clock::now(); };
         auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
@@ -965,6 +970,23 @@ struct IterativeMatrixFunctions {
                 // new column of the projected matrix: H(j, i) = <b_j, sigma_i>, j <= i (H is symmetric)
                 std::vector<const double *> ptrs(bs.begin(), bs.begin() + i + 1);
                 check(b2x_vec_multi_dot(ptrs.data(), i + 1, sg[i], n, row.data(), nullptr));
+                if (gs_pending == i) { // (b_i came from the device-side Gram-Schmidt finish: its status is known now)
+                    gs_pending = -1;
+                    int degenerate = 0;
+                    check(b2x_vec_gs_status(&degenerate, 1));
+                    if (degenerate) { // the careful way: two more passes against b_0..b_{i-1}, explicit norm, sigma again
+                        double *v = bs[i], *w = t;
+                        orthogonalise(v, w, i);
+                        if (v != bs[i])
+                            check(b2x_vec_copy(v, bs[i], n, nullptr));
+                        check(b2x_vec_scal(1.0 / std::sqrt(dot(bs[i], bs[i])), bs[i], n, nullptr));
+                        if (pcomm != nullptr)
+                            pcomm->broadcast(bs[i], n);
+                        check(b2x_vec_zero(sg[i], n, nullptr));
+                        op(bs[i], sg[i]);
+                        check(b2x_vec_multi_dot(ptrs.data(), i + 1, sg[i], n, row.data(), nullptr));
+                    }
+                }
                 for (int j = 0; j <= i; j++)
                     H[(size_t)j * M + i] = H[(size_t)i * M + j] = row[j];
             }
@@ -1004,12 +1026,12 @@ struct IterativeMatrixFunctions {
             }
             const int ick = idx[ck];
             ritz_residual(ick);
-            // The usual step (Olsen preconditioner, no projected-out states, no collapse due) in THREE host round trips
-            // instead of six: the residual norm, the two Olsen products and the projections of the preconditioned residual
-            // q2 and of t on the basis are ONE b2x_vec_pair_dots; the Olsen correction and the first Gram-Schmidt pass are
-            // then ONE linear combination (both are linear in q2 and t: <b_j, q2 - g t> = <b_j, q2> - g <b_j, t>), the second
-            // pass and the norm of the new vector one more pair-dot and one more combination.  Same subspace as the
-            // step-by-step form below up to rounding (B2X_DAV_FUSED=0 selects that form; tools/davidson_overhead.py).
+            // The usual step (Olsen preconditioner, no projected-out states, no collapse due) in TWO host round trips instead of
+            // six: the residual norm, the two Olsen products and the projections of the preconditioned residual q2 and of t on
+            // the basis are ONE b2x_vec_pair_dots; the Olsen correction and the first Gram-Schmidt pass are then ONE linear
+            // combination (both are linear in q2 and t: <b_j, q2 - g t> = <b_j, q2> - g <b_j, t>); the second pass and the
+            // normalisation stay on the device (b2x_vec_gs_finish).  Same subspace as the step-by-step form below up to rounding
+            // (B2X_DAV_FUSED=0 selects that form; tools/davidson_overhead.py).
             const bool fused = fused_ok && m < deflation_max_size && m + 2 <= 64 && 2 * m + 3 <= 128;
             if (fused) {
                 check(b2x_vec_olsen_prepare_to(q, q2, t, x, aa_dev, ld[ick], n, nullptr));
@@ -1079,26 +1101,16 @@ struct IterativeMatrixFunctions {
                     ptrs.push_back(q2), ptrs.push_back(t);
                     gs_c[m] = 1.0, gs_c[m + 1] = -g;
                     check(b2x_vec_lincomb(ptrs.data(), m + 2, gs_c.data(), q, n, nullptr));
-                    // second pass and the norm: <b_j, v1> and <v1, v1> together; |v1 - sum c_j b_j|^2 = <v1, v1> - sum c_j^2
-                    // for an orthonormal basis (the c_j are rounding-sized after the first pass: no cancellation)
-                    fu.assign(bs.begin(), bs.begin() + m), fv.assign((size_t)m, q);
-                    fu.push_back(q), fv.push_back(q);
-                    fr.resize((size_t)m + 1);
-                    check(b2x_vec_pair_dots(fu.data(), fv.data(), m + 1, n, fr.data(), nullptr));
-                    double nrm2 = fr[m];
-                    for (int j = 0; j < m; j++)
-                        nrm2 -= fr[j] * fr[j];
-                    if (nrm2 > 1e-24 * std::fabs(fr[m]) && nrm2 > 0) {
-                        const double inv = 1.0 / std::sqrt(nrm2);
-                        ptrs.assign(bs.begin(), bs.begin() + m);
-                        for (int j = 0; j < m; j++)
-                            gs_c[j] = -fr[j] * inv;
-                        ptrs.push_back(q);
-                        gs_c[m] = inv;
-                        ensure(m);
-                        check(b2x_vec_lincomb(ptrs.data(), m + 1, gs_c.data(), bs[m], n, nullptr));
-                        m++, appended = true;
-                    } // (else: the new direction lies in the subspace to rounding; finish it the careful way)
+                    // second pass and normalisation WITHOUT a host round trip: <b_j, v1> and <v1, v1> stay on the device and the
+                    // kernel that forms b_m = (v1 - sum c_j b_j) / |.| reads them there (|.|^2 = <v1, v1> - sum c_j^2 for an
+                    // orthonormal basis; the c_j are rounding-sized after the first pass: no cancellation).  Should the new
+                    // direction lie in the subspace to rounding, the kernel raises a flag that is looked at after the next wait
+                    // (the projected-matrix column of b_m, below) and b_m is redone the careful way there.
+                    ptrs.assign(bs.begin(), bs.begin() + m);
+                    ensure(m);
+                    check(b2x_vec_gs_finish(ptrs.data(), m, q, bs[m], n, nullptr));
+                    gs_pending = m;
+                    m++, appended = true;
                 }
                 if (!appended) {
                     orthogonalise(q, t, m);

@@ -290,6 +290,12 @@ int b2x_vec_olsen_prepare_to(const double *q, double *q_out, double *t, const do
  * would be one device synchronisation each) */
 int b2x_vec_pair_dots(const double *const *us, const double *const *vs, int n_pairs, size_t n, double *host_result,
                       void *stream);
+/* out = (v - sum_{j<m} <b_j, v> b_j) / norm for an orthonormal set b (m <= 63): the second Gram-Schmidt pass and the
+ * normalisation of a new Davidson basis vector with the coefficients kept on the device — no host round trip; asynchronous on
+ * `stream`.  When the norm is not safely positive (v in the span of b to rounding) the unnormalised difference is written and a
+ * flag raised that b2x_vec_gs_status reports after the caller's next wait on the stream (reset != 0 clears it). */
+int b2x_vec_gs_finish(const double *const *bs, int m, const double *v, double *out, size_t n, void *stream);
+int b2x_vec_gs_status(int *degenerate, int reset);
 /* gram[j] = <vs[j], x> for j < nv; vs = nv device pointers (host array of device pointers) */
 int b2x_vec_multi_dot(const double *const *vs, int nv, const double *x, size_t n, double *host_result,
                       void *stream);

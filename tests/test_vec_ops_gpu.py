@@ -52,3 +52,35 @@ def test_pair_dots_and_olsen_to(gpu):
     assert np.array_equal(dq.download(), q)
     assert np.allclose(dqo.download(), np.where(ok, q / np.where(ok, den, 1.0), q), rtol=1e-14, atol=0)
     assert np.allclose(dt.download(), np.where(ok, c / np.where(ok, den, 1.0), c), rtol=1e-14, atol=0)
+
+
+def test_gs_finish_on_device(gpu):
+    """b2x_vec_gs_finish: second Gram-Schmidt pass + normalisation with the coefficients left on the device, against numpy;
+    the degenerate case (v in the span of the basis) raises the status flag instead of dividing by a rounding-sized norm"""
+    rng = np.random.default_rng(9)
+    n, m = 50021, 7
+    q, _ = np.linalg.qr(rng.standard_normal((n, m)))
+    v = rng.standard_normal(n)
+    bufs = [gpu.DeviceBuffer(n, np.ascontiguousarray(q[:, j])) for j in range(m)]
+    bs = (C.c_void_p * m)(*[b.ptr for b in bufs])
+    dv, dout = gpu.DeviceBuffer(n, v), gpu.DeviceBuffer(n)
+    flag = C.c_int(-1)
+    gpu.check(gpu.lib().b2x_vec_gs_finish(bs, C.c_int(m), C.c_void_p(dv.ptr), C.c_void_p(dout.ptr), C.c_size_t(n), None))
+    gpu.device_sync()
+    gpu.check(gpu.lib().b2x_vec_gs_status(C.byref(flag), C.c_int(1)))
+    want = v - q @ (q.T @ v)
+    want /= np.linalg.norm(want)
+    got = dout.download()
+    assert flag.value == 0 and np.abs(got - want).max() < 1e-12 and abs(np.linalg.norm(got) - 1) < 1e-12
+    # m = 0: plain normalisation
+    gpu.check(gpu.lib().b2x_vec_gs_finish(None, C.c_int(0), C.c_void_p(dv.ptr), C.c_void_p(dout.ptr), C.c_size_t(n), None))
+    gpu.device_sync()
+    assert np.abs(dout.download() - v / np.linalg.norm(v)).max() < 1e-13
+    # degenerate: v = a combination of the basis
+    dv.upload(q @ rng.standard_normal(m))
+    gpu.check(gpu.lib().b2x_vec_gs_finish(bs, C.c_int(m), C.c_void_p(dv.ptr), C.c_void_p(dout.ptr), C.c_size_t(n), None))
+    gpu.device_sync()
+    gpu.check(gpu.lib().b2x_vec_gs_status(C.byref(flag), C.c_int(1)))
+    assert flag.value == 1 and np.isfinite(dout.download()).all()
+    gpu.check(gpu.lib().b2x_vec_gs_status(C.byref(flag), C.c_int(0)))
+    assert flag.value == 0  # cleared by the reset above
