@@ -276,6 +276,7 @@ struct b2x_plan {
     OEntry *d_sum_entries = nullptr;
     std::vector<SuperStep> steps;
     std::vector<uint32_t> step_max_elems; // per super-step: elements of its largest psi' tile
+    std::vector<uint32_t> step_max_items; // ... and the largest number of partial slabs of one of its tiles
     std::vector<StageCopy> stage_in; // input-vector operands copied into the scratch at the start of every execute
     // the short-tile class of a stage runs beside the tall one on a stream of its own (fork / join with events)
     hipStream_t aux_stream = nullptr;
@@ -524,10 +525,13 @@ static int plan_upload(b2x_plan **out, const b2x_arena *arena, const CompiledPla
             rc = upload(&p->d_sum_entries, cp.sum_entries);
         p->steps = cp.steps;
         for (const SuperStep &ss : cp.steps) { // largest tile of every step's reduce (launch_reduce)
-            uint32_t mx = 0;
-            for (uint32_t ti = ss.tile_begin; ti < ss.tile_end; ti++)
+            uint32_t mx = 0, mi = 0;
+            for (uint32_t ti = ss.tile_begin; ti < ss.tile_end; ti++) {
                 mx = std::max(mx, (uint32_t)cp.gtiles[ti].rows * (uint32_t)cp.gtiles[ti].cols);
+                mi = std::max(mi, (uint32_t)cp.gtiles[ti].n_items);
+            }
             p->step_max_elems.push_back(mx);
+            p->step_max_items.push_back(mi);
         }
         p->scratch_elems = cp.scratch_elems, p->gslab_elems = cp.gslab_elems, p->slab_elems = cp.slab_elems;
         p->scratch_pads = cp.scratch_pads;
@@ -838,7 +842,8 @@ static int run_plan(b2x_plan *p, const double *psi, double *sigma, double scale,
         if ((rc = launch_stage(p, ss.s1_v, psi, st)) != B2X_OK)
             return rc;
         HIPCHK(launch_reduce(p->d_gtiles + ss.tile_begin, ss.tile_end - ss.tile_begin, p->d_gslabs, sigma, scale, st,
-                             si < p->step_max_elems.size() ? p->step_max_elems[si] : 0));
+                             si < p->step_max_elems.size() ? p->step_max_elems[si] : 0,
+                             si < p->step_max_items.size() ? p->step_max_items[si] : 0));
     }
     return B2X_OK;
 }

@@ -19,8 +19,10 @@ hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_beg
                      bool short_narrow = false, int short_frags = kGGShortFrags);
 hipError_t launch_outer(const OWork *work, uint32_t n_work, const OEntry *entries, const double *arena, const double *in,
                         double *out, int rows_in_flight, hipStream_t st);
+// max_elems / max_items: elements of the largest tile / slabs of the tile with the most slabs (0: unknown) — they pick the grid
+// and, for tiles with many slabs, the kernel that splits the slabs of an element over several threads
 hipError_t launch_reduce(const DTile *tiles, uint32_t n_tiles, const double *slabs, double *sigma, double scale,
-                         hipStream_t st, uint32_t max_elems = 0);
+                         hipStream_t st, uint32_t max_elems = 0, uint32_t max_items = 0);
 hipError_t launch_generic(const b2x_pair *pairs, uint32_t n_pairs, const double *arena, const double *psi,
                           double *sigma, double scale, hipStream_t st);
 hipError_t launch_diag(const DiagComp *comps, uint32_t n_comps, const DiagTermD *terms, const double *arena, double *diag,

@@ -690,6 +690,47 @@ __global__ __launch_bounds__(256) void hpsi_reduce(const DTile *__restrict__ til
     }
 }
 
+// The same sum for tiles with MANY slabs (small psi' and a long contraction: a site near the ends of a chain has one or two tiles
+// that all work items of the plan accumulate into, hundreds to thousands of slabs each; the tiles of one plan differ by orders of
+// magnitude).  hpsi_reduce walks the slabs of an element one after the other in one thread; here IY threads share an element —
+// thread iy takes slabs iy, iy + IY, ... — and their partial sums are added in a fixed binary tree through LDS: still no atomics,
+// still the same bits on every run.  IY is chosen PER TILE from its slab count (a power of two, 1 .. 64: about four slabs per
+// thread); a workgroup pass covers EX = 256 / IY consecutive elements.
+__global__ __launch_bounds__(256) void hpsi_reduce_split(const DTile *__restrict__ tiles, const double *__restrict__ slabs,
+                                                          double *__restrict__ sigma, double scale) {
+    __shared__ double part[256];
+    const DTile t = tiles[blockIdx.x];
+    const int n = t.rows * t.cols;
+    if (t.n_items == 0)
+        return;
+    int lg = 0; // IY = 2^lg
+    while (lg < 6 && (4 << lg) < t.n_items)
+        lg++;
+    const int IY = 1 << lg, EX = 256 >> lg;
+    const int ex = threadIdx.x & (EX - 1), iy = threadIdx.x >> (8 - lg);
+    for (int e0 = blockIdx.y * EX; e0 < n; e0 += gridDim.y * EX) { // (uniform per workgroup: the barriers below are safe)
+        const int e = e0 + ex;
+        double sum = 0.0;
+        if (e < n) {
+            const double *s = slabs + t.slab_off + e;
+            for (int i = iy; i < t.n_items; i += IY)
+                sum += s[(int64_t)i * n];
+        }
+        part[threadIdx.x] = sum; // [iy][ex]
+        __syncthreads();
+        for (int h = IY >> 1; h > 0; h >>= 1) {
+            if (iy < h)
+                part[threadIdx.x] += part[threadIdx.x + h * EX];
+            __syncthreads();
+        }
+        if (iy == 0 && e < n) {
+            int r = e / t.cols, cc = e - r * t.cols;
+            sigma[t.sigma_off + (int64_t)r * t.ld + cc] += scale * part[ex];
+        }
+        __syncthreads();
+    }
+}
+
 // ------------- generic fallback / on-device cross-check (any plan; atomics, not reproducible) -----
 // one workgroup per pair: W chunk (16 rows of W at a time) in LDS, scalar FMAs, atomicAdd into psi'.
 __global__ __launch_bounds__(256) void hpsi_generic(const b2x_pair *__restrict__ pairs, const double *__restrict__ arena,
@@ -1071,9 +1112,21 @@ hipError_t launch_gg(const GSeg *segs, const GItem *items, const uint32_t *v_beg
 // max_elems = rows x columns of the largest tile of the list: small tiles get fewer workgroups each (a 32 x 32 tile is four
 // blocks of 256 elements; sixteen per tile, twelve of them idle, made the reduce 9 % of an H.psi at M=250)
 hipError_t launch_reduce(const DTile *tiles, uint32_t n_tiles, const double *slabs, double *sigma, double scale,
-                         hipStream_t st, uint32_t max_elems) {
+                         hipStream_t st, uint32_t max_elems, uint32_t max_items) {
     if (n_tiles == 0)
         return hipSuccess;
+    // many slabs per tile: the slabs of an element are split over up to 64 threads (hpsi_reduce_split; the grid covers the
+    // narrowest element block, EX = 4, of the largest tile, capped: tiles with fewer slabs use wider blocks and fewer passes)
+    if (max_items >= 16) {
+        const uint32_t elems = max_elems == 0 ? 16384u : max_elems;
+        uint32_t ex = 64;
+        while (ex > 4 && 4u * (256u / ex) < max_items)
+            ex >>= 1;
+        const uint32_t gy = std::min(64u, std::max(1u, (elems + ex - 1) / ex));
+        note_slots((const void *)hpsi_reduce_split, -1, 2, 3);
+        hipLaunchKernelGGL(hpsi_reduce_split, dim3(n_tiles, gy), dim3(256), 0, st, tiles, slabs, sigma, scale);
+        return hipGetLastError();
+    }
     const uint32_t gy = max_elems == 0 ? 16u : std::min(16u, std::max(1u, (max_elems + 255u) / 256u));
     note_slots((const void *)hpsi_reduce, -1, 2, 3);
     hipLaunchKernelGGL(hpsi_reduce, dim3(n_tiles, gy), dim3(256), 0, st, tiles, slabs, sigma, scale);
