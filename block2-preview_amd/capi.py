@@ -24,7 +24,7 @@ DECLARED_SYMBOLS = [
     "b2x_plan_cache_stats", "b2x_plan_cache_clear", "b2x_trim",
     "b2x_gemm_plan_create", "b2x_outer_build",
     "b2x_vec_dot", "b2x_vec_axpy", "b2x_vec_scal", "b2x_vec_copy", "b2x_vec_zero", "b2x_vec_precondition",
-    "b2x_vec_multi_dot", "b2x_vec_pair_dots", "b2x_vec_olsen_prepare_to", "b2x_vec_gather", "b2x_vec_gs_finish", "b2x_vec_gs_status", "b2x_outer_plan_create", "b2x_outer_plan_execute", "b2x_outer_plan_destroy", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
+    "b2x_vec_multi_dot", "b2x_vec_pair_dots", "b2x_vec_olsen_prepare_to", "b2x_vec_gather", "b2x_vec_gs_finish", "b2x_vec_ritz_olsen", "b2x_vec_gs_status", "b2x_outer_plan_create", "b2x_outer_plan_execute", "b2x_outer_plan_destroy", "b2x_vec_lincomb", "b2x_vec_olsen_prepare", "b2x_diag_build",
     "b2x_comm_init", "b2x_comm_init_session", "b2x_comm_unique_id", "b2x_comm_init_id", "b2x_comm_rank", "b2x_allreduce_sum", "b2x_broadcast",
     "b2x_barrier", "b2x_comm_destroy",
 ]

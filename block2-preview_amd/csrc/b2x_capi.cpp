@@ -1298,6 +1298,13 @@ int b2x_vec_pair_dots(const double *const *us, const double *const *vs, int n_pa
     memcpy(host_result, g_dot_host, n_pairs * sizeof(double));
     return B2X_OK;
 }
+int b2x_vec_ritz_olsen(const double *const *bs, const double *const *ss, int m, const double *alpha, double theta, const double *diag,
+                       double *x, double *q, double *q2, double *t, size_t n, void *stream) {
+    if (m < 1 || m > 64 || !bs || !ss || !alpha || !diag || !x || !q || !q2 || !t)
+        return fail(B2X_ERR_INVALID, "b2x_vec_ritz_olsen: need 1 <= m <= 64 and non-null vectors");
+    HIPCHK(launch_ritz_olsen(bs, ss, m, alpha, theta, diag, x, q, q2, t, n, (hipStream_t)stream));
+    return B2X_OK;
+}
 // out = (v - sum_j <b_j, v> b_j) / |.|, everything on the device and asynchronous on `stream`; *status (pinned host memory owned by
 // the library, see b2x_vec_gs_status) becomes 1 when the norm was not safely positive.
 static int *g_gs_flag_dev = nullptr, *g_gs_flag_host = nullptr;

@@ -32,6 +32,9 @@ hipError_t launch_scal(double a, double *x, size_t n, hipStream_t st);
 hipError_t launch_precond(double *q, const double *diag, double shift, size_t n, hipStream_t st);
 hipError_t launch_olsen(const double *q, double *q_out, double *t, const double *c, const double *diag, double ld, size_t n,
                         hipStream_t st);
+// x = sum a_j b_j, q = sum a_j s_j - theta x, q2 = q / (theta - diag), t = x / (theta - diag) in one pass (m <= 64)
+hipError_t launch_ritz_olsen(const double *const *bs, const double *const *ss, int m, const double *alpha, double theta,
+                             const double *diag, double *x, double *q, double *q2, double *t, size_t n, hipStream_t st);
 // second Gram-Schmidt pass + normalisation without a host round trip (m <= 63): dots / partial = device scratch of the dot products
 hipError_t launch_gs_finish(const double *const *bs, int m, const double *v, double *partial, double *dots, double *out, size_t n,
                             int *flag, hipStream_t st);

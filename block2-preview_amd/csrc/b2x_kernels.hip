@@ -958,6 +958,27 @@ __global__ __launch_bounds__(256) void vec_multidot_k(VecPtrs vp, int nv, const 
     if (threadIdx.x == 0)
         partial[(size_t)j * gridDim.x + blockIdx.x] = sh[0];
 }
+// Ritz vector, residual and the first half of the Olsen preconditioner of a Davidson step in ONE pass over the basis and its
+// images: x = sum_j a_j b_j, q = sum_j a_j s_j - theta x, and with d = theta - diag (where |d| > 1e-12, else 1): q2 = q / d,
+// t = x / d.  (Two linear combinations and vec_olsen_k before: three launches, x and q read back from memory.)
+struct RitzPtrs {
+    const double *b[64];
+    const double *s[64];
+    double a[64];
+};
+__global__ void vec_ritz_olsen_k(RitzPtrs rp, int m, double theta, const double *__restrict__ diag, double *__restrict__ x,
+                                 double *__restrict__ q, double *__restrict__ q2, double *__restrict__ t, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        double xv = 0.0, sv = 0.0;
+        for (int j = 0; j < m; j++)
+            xv += rp.a[j] * rp.b[j][i], sv += rp.a[j] * rp.s[j][i];
+        const double qv = sv - theta * xv;
+        const double d = theta - diag[i];
+        const bool ok = fabs(d) > 1e-12;
+        x[i] = xv, q[i] = qv;
+        q2[i] = ok ? qv / d : qv, t[i] = ok ? xv / d : xv;
+    }
+}
 // Second Gram-Schmidt pass + normalisation with the coefficients still ON THE DEVICE (dots[j] = <b_j, v>, dots[m] = <v, v>, as
 // vec_pairdot_k + vec_multidot_final_k left them): out = (v - sum_j dots[j] b_j) / sqrt(<v, v> - sum_j dots[j]^2).  The norm of
 // the result follows from the dots for an orthonormal basis; when it is not safely positive (the new direction lies in the span of
@@ -1184,6 +1205,14 @@ hipError_t launch_multidot(const double *const *vs, int nv, const double *x, siz
     return hipGetLastError();
 }
 
+hipError_t launch_ritz_olsen(const double *const *bs, const double *const *ss, int m, const double *alpha, double theta,
+                             const double *diag, double *x, double *q, double *q2, double *t, size_t n, hipStream_t st) {
+    RitzPtrs rp;
+    for (int j = 0; j < m; j++)
+        rp.b[j] = bs[j], rp.s[j] = ss[j], rp.a[j] = alpha[j];
+    hipLaunchKernelGGL(vec_ritz_olsen_k, dim3(vec_grid(n)), dim3(256), 0, st, rp, m, theta, diag, x, q, q2, t, n);
+    return hipGetLastError();
+}
 hipError_t launch_gs_finish(const double *const *bs, int m, const double *v, double *partial, double *dots, double *out, size_t n,
                             int *flag, hipStream_t st) {
     PairPtrs pp;

@@ -1025,7 +1025,6 @@ struct IterativeMatrixFunctions {
                 }
             }
             const int ick = idx[ck];
-            ritz_residual(ick);
             // The usual step (Olsen preconditioner, no projected-out states, no collapse due) in TWO host round trips instead of
             // six: the residual norm, the two Olsen products and the projections of the preconditioned residual q2 and of t on
             // the basis are ONE b2x_vec_pair_dots; the Olsen correction and the first Gram-Schmidt pass are then ONE linear
@@ -1034,7 +1033,8 @@ struct IterativeMatrixFunctions {
             // (B2X_DAV_FUSED=0 selects that form; tools/davidson_overhead.py).
             const bool fused = fused_ok && m < deflation_max_size && m + 2 <= 64 && 2 * m + 3 <= 128;
             if (fused) {
-                check(b2x_vec_olsen_prepare_to(q, q2, t, x, aa_dev, ld[ick], n, nullptr));
+                std::vector<const double *> pb(bs.begin(), bs.begin() + m), ps(sg.begin(), sg.begin() + m);
+                check(b2x_vec_ritz_olsen(pb.data(), ps.data(), m, &alpha[(size_t)ick * m], ld[ick], aa_dev, x, q, q2, t, n, nullptr));
                 fu.assign({q, q2, t}), fv.assign({q, x, x});
                 for (int j = 0; j < m; j++)
                     fu.push_back(bs[j]), fv.push_back(q2);
@@ -1044,6 +1044,7 @@ struct IterativeMatrixFunctions {
                 check(b2x_vec_pair_dots(fu.data(), fv.data(), 3 + 2 * m, n, fr.data(), nullptr));
                 qq = fr[0];
             } else {
+                ritz_residual(ick);
                 project_ors(q);
                 qq = dot(q, q);
             }

@@ -290,6 +290,11 @@ int b2x_vec_olsen_prepare_to(const double *q, double *q_out, double *t, const do
  * would be one device synchronisation each) */
 int b2x_vec_pair_dots(const double *const *us, const double *const *vs, int n_pairs, size_t n, double *host_result,
                       void *stream);
+/* One pass over a Davidson basis b_j and its images s_j (m <= 64): the Ritz vector x = sum alpha_j b_j, its residual
+ * q = sum alpha_j s_j - theta x, and the first half of olsen_precondition on both (as b2x_vec_olsen_prepare_to, c = x, ld = theta):
+ * q2 = q / (theta - diag), t = x / (theta - diag). */
+int b2x_vec_ritz_olsen(const double *const *bs, const double *const *ss, int m, const double *alpha, double theta,
+                       const double *diag, double *x, double *q, double *q2, double *t, size_t n, void *stream);
 /* out = (v - sum_{j<m} <b_j, v> b_j) / norm for an orthonormal set b (m <= 63): the second Gram-Schmidt pass and the
  * normalisation of a new Davidson basis vector with the coefficients kept on the device — no host round trip; asynchronous on
  * `stream`.  When the norm is not safely positive (v in the span of b to rounding) the unnormalised difference is written and a

@@ -84,3 +84,26 @@ def test_gs_finish_on_device(gpu):
     assert flag.value == 1 and np.isfinite(dout.download()).all()
     gpu.check(gpu.lib().b2x_vec_gs_status(C.byref(flag), C.c_int(0)))
     assert flag.value == 0  # cleared by the reset above
+
+
+def test_ritz_olsen_one_pass(gpu):
+    """b2x_vec_ritz_olsen against numpy: x = sum a_j b_j, q = sum a_j s_j - theta x, q2 = q / (theta - diag), t = x / (theta - diag)"""
+    rng = np.random.default_rng(10)
+    n, m = 70001, 11
+    b, s_ = rng.standard_normal((m, n)), rng.standard_normal((m, n))
+    a, theta, diag = rng.standard_normal(m), 0.37, rng.uniform(-1, 1, n)
+    diag[3] = theta  # a singular element: left unscaled
+    db, ds = [gpu.DeviceBuffer(n, np.ascontiguousarray(v)) for v in b], [gpu.DeviceBuffer(n, np.ascontiguousarray(v)) for v in s_]
+    pb, ps = (C.c_void_p * m)(*[v.ptr for v in db]), (C.c_void_p * m)(*[v.ptr for v in ds])
+    dd = gpu.DeviceBuffer(n, diag)
+    out = [gpu.DeviceBuffer(n) for _ in range(4)]
+    gpu.check(gpu.lib().b2x_vec_ritz_olsen(pb, ps, C.c_int(m), a.ctypes.data_as(C.c_void_p), C.c_double(theta), C.c_void_p(dd.ptr),
+                                           *[C.c_void_p(o.ptr) for o in out], C.c_size_t(n), None))
+    gpu.device_sync()
+    x = a @ b
+    q = a @ s_ - theta * x
+    d = theta - diag
+    ok = np.abs(d) > 1e-12
+    want = [x, q, np.where(ok, q / np.where(ok, d, 1.0), q), np.where(ok, x / np.where(ok, d, 1.0), x)]
+    for o, w in zip(out, want):
+        assert np.abs(o.download() - w).max() <= 1e-12 * max(1.0, np.abs(w).max())
