@@ -590,6 +590,15 @@ int b2x_device_init(int ordinal) {
     if (ordinal < 0 || ordinal >= c)
         return fail(B2X_ERR_INVALID, "device ordinal out of range");
     HIPCHK(hipSetDevice(ordinal));
+    // Another thread of the process may be capturing a plan into a HIP graph (thread-local mode) while this one copies or
+    // allocates — the sweep loop's helper threads do.  A thread in the default (global) capture-interaction mode is refused
+    // such calls while ANY capture is open ("would make the legacy stream depend on a capturing blocking stream"): every
+    // thread that initialises the library looks at its own captures only.
+    {
+        hipStreamCaptureMode mode = hipStreamCaptureModeThreadLocal;
+        (void)hipThreadExchangeStreamCaptureMode(&mode);
+        (void)hipGetLastError();
+    }
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, ordinal));
     if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)

@@ -159,6 +159,27 @@ def _helper_pool():
     return _pool_shared
 
 
+class _one_blas_thread:
+    """context: numpy's BLAS / LAPACK on one thread (threadpoolctl; a no-op without it or with B2X_HOST_BLAS_THREADS=0)"""
+
+    def __enter__(self):
+        self._ctx = None
+        if os.environ.get("B2X_HOST_BLAS_THREADS") == "0":
+            return self
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:
+            return self
+        self._ctx = threadpool_limits(limits=1, user_api="blas")
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self._ctx is not None:
+            self._ctx.__exit__(*a)
+        return False
+
+
 _heap_retained = False
 
 
@@ -941,18 +962,19 @@ class DMRG:
 
         kept_of, spectrum, rot = {}, {}, {}
         kept_w, mmps = 0.0, 0
-        for s in range(len(ainfo["q"])):
-            key = (int(an[s]), int(atw[s]), int(apg[s]))
-            rows, cols = int(ainfo["nbra"][s]), int(ainfo["nket"][s])
-            fused, kept = (cols, rows) if right else (rows, cols)
-            w, u = np.linalg.eigh(rho_of(key, fused))
-            kept_of[key], spectrum[key] = kept, w[::-1]
-            kept_w, mmps = kept_w + float(w[::-1][:kept].sum()), mmps + kept
-            u = u[:, ::-1][:, :kept]  # largest weights first
-            rot[key] = u
-            blk = u.T if right else u
-            o = base + int(ainfo["ntot"][s])
-            out[o:o + rows * cols] = blk.reshape(-1)
+        with _one_blas_thread():  # (sector-sized eigenproblems: one LAPACK thread each is the fastest they run)
+            for s in range(len(ainfo["q"])):
+                key = (int(an[s]), int(atw[s]), int(apg[s]))
+                rows, cols = int(ainfo["nbra"][s]), int(ainfo["nket"][s])
+                fused, kept = (cols, rows) if right else (rows, cols)
+                w, u = np.linalg.eigh(rho_of(key, fused))
+                kept_of[key], spectrum[key] = kept, w[::-1]
+                kept_w, mmps = kept_w + float(w[::-1][:kept].sum()), mmps + kept
+                u = u[:, ::-1][:, :kept]  # largest weights first
+                rot[key] = u
+                blk = u.T if right else u
+                o = base + int(ainfo["ntot"][s])
+                out[o:o + rows * cols] = blk.reshape(-1)
         trace = sum(float(data @ data) for data, _, _ in srcs)
         self.last_split = {"error": max(0.0, trace - kept_w), "mmps": mmps}
         if self.use_previous:
