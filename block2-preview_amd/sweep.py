@@ -950,14 +950,20 @@ class DMRG:
             atw = np.where(atw >= 32768, atw - 65536, atw)
         srcs = self._density_blocks(right)
 
+        # blocks by bond label, in the order (wavefunction, block) the sums are taken in (a noisy sweep adds ~50 perturbed
+        # wavefunctions: a label search per (sector, wavefunction) was most of the split's time)
+        by_label = {}
+        for data, inf, (bn, btw, bpg) in srcs:
+            for i, k in enumerate(zip(bn.tolist(), btw.tolist(), bpg.tolist())):
+                by_label.setdefault(k, []).append((data, inf, i))
+
         def rho_of(key, fused):
             rho = np.zeros((fused, fused))
-            for data, inf, (bn, btw, bpg) in srcs:
-                for i in np.nonzero((bn == key[0]) & (btw == key[1]) & (bpg == key[2]))[0]:
-                    b = data[inf["ntot"][i]:inf["ntot"][i] + inf["nbra"][i] * inf["nket"][i]].reshape(
-                        int(inf["nbra"][i]), int(inf["nket"][i]))
-                    assert (b.shape[1] if right else b.shape[0]) == fused
-                    rho += b.T @ b if right else b @ b.T
+            for data, inf, i in by_label.get(key, ()):
+                b = data[inf["ntot"][i]:inf["ntot"][i] + inf["nbra"][i] * inf["nket"][i]].reshape(
+                    int(inf["nbra"][i]), int(inf["nket"][i]))
+                assert (b.shape[1] if right else b.shape[0]) == fused
+                rho += b.T @ b if right else b @ b.T
             return rho
 
         kept_of, spectrum, rot = {}, {}, {}
