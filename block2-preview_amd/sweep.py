@@ -159,6 +159,9 @@ def _helper_pool():
     return _pool_shared
 
 
+_tp_controller = None
+
+
 class _one_blas_thread:
     """context: numpy's BLAS / LAPACK on one thread (threadpoolctl; a no-op without it or with B2X_HOST_BLAS_THREADS=0)"""
 
@@ -166,11 +169,15 @@ class _one_blas_thread:
         self._ctx = None
         if os.environ.get("B2X_HOST_BLAS_THREADS") == "0":
             return self
+        global _tp_controller
         try:
-            from threadpoolctl import threadpool_limits
-        except ImportError:
+            if _tp_controller is None:  # (made once: a controller scans the loaded libraries, 0.6 ms)
+                from threadpoolctl import ThreadpoolController
+
+                _tp_controller = ThreadpoolController()
+            self._ctx = _tp_controller.limit(limits=1, user_api="blas")
+        except Exception:
             return self
-        self._ctx = threadpool_limits(limits=1, user_api="blas")
         self._ctx.__enter__()
         return self
 
@@ -418,6 +425,7 @@ class DMRG:
         (complementary) operators that are sums of its own operators or their transposes
         (TensorFunctions::numerical_transform); the sums run on the device, in place in the block's vector"""
         t0 = time.perf_counter()
+        ready = self._take_ready(d.get("_num", -1))
         total = int(d["meta"][3])
         lens = [(_info(d, i)["len"] if o >= 0 else 0) for i, o in zip(d["t.info"], d["t.off"])]
         have = {int(k): (int(o), int(l)) for k, o, l in zip(d["t.key"], d["t.off"], lens) if o >= 0 and l > 0}
@@ -429,10 +437,15 @@ class DMRG:
                 assert sl == l
                 do.append(o), so_.append(so), ln.append(l)
         capi.gather_d2d(out.buf.ptr, rot.buf.ptr, do, so_, ln)
-        terms = _records(self.host.symbolic_transform(self.sym, d), OUTER_TERM_DTYPE)
         dummy = capi.Arena.from_host([np.zeros(1)])
-        capi.outer_build(dummy, terms, out.buf.ptr, out.buf.ptr, True, total, total)
+        if ready is not None:
+            ready[1].execute(dummy, out.buf.ptr, out.buf.ptr)
+        else:
+            terms = _records(self.host.symbolic_transform(self.sym, d), OUTER_TERM_DTYPE)
+            capi.outer_build(dummy, terms, out.buf.ptr, out.buf.ptr, True, total, total)
         capi.device_sync()
+        if ready is not None:
+            ready[1].close()
         dummy.close(), rot.close()
         self.tm.add("transform", t0)
         return out
@@ -508,7 +521,7 @@ class DMRG:
             num, kind, fn = fx.events[k]
             if kind in ("lblk", "rblk") and k + 1 < len(fx.events) and fx.events[k + 1][1] in ("lrot", "rrot"):
                 continue  # (the re-contraction block2 does before a rotation: the enlarged block is still in HBM here)
-            if kind in ("lrot", "rrot", "lblk", "rblk", "eham", "enoise") and num not in self._ahead:
+            if kind in ("lrot", "rrot", "lblk", "rblk", "eham", "enoise", "lntr", "rntr", "lint", "rint") and num not in self._ahead:
                 todo.append((num, kind, fn))
             if kind == "eham":  # (+ the perturbative-noise step of the same site, on a noisy sweep)
                 if k + 1 < len(fx.events) and fx.events[k + 1][1] == "enoise" and fx.events[k + 1][0] not in self._ahead:
@@ -554,6 +567,10 @@ class DMRG:
                 plan = capi.Plan(arena, pairs, xl, vl)
                 plan.close(), arena.close()
                 return pairs
+            if kind in ("lntr", "rntr", "lint", "rint"):  # operator sums inside a rotated block: terms + compiled work list
+                total = int(d["meta"][3])
+                terms = _records(self.host.symbolic_transform(self.sym, d), OUTER_TERM_DTYPE)
+                return terms, capi.OuterPlan(terms, 1, total, total)
             terms, vlen, sum_terms, tmp_len = self._record_blocking(d)
             # the work list of the block products compiled and uploaded now (the site operators are the arena of this step)
             op = capi.OuterPlan(terms, len(d["site"]), int(d["x.len"][0]) + tmp_len, vlen)
