@@ -58,6 +58,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix peak (vendor figure; measured ceiling in DESIGN.md)
+HBM_PEAK_TBS = 8.0            # HBM3E peak (MI355X_MICROARCH.md)
 GOLD = os.path.join(ROOT, "tests", "golden")
 WORKLOADS = {
     "cr2_m4000": ("cr2_su2_m250_sw1_site20.struct.npz", 16, 4000,
@@ -713,6 +714,18 @@ def main():
                          "atomic_fallback": st["fallback"]},
             "sigma_checksum": checksum,
         }
+        if traffic:
+            # the other roof, from the measured FETCH traffic of one H.psi (a PMC pass of an earlier run of this workload,
+            # profiles/pmc_traffic.json) and THIS run's kernel time: flops per fetched byte against the ridge of the card
+            # (78.6 TFLOP/s / 8 TB/s = 9.8).  Below the ridge the kernel is bound by the bytes it fetches, whatever the MFMA
+            # fraction says — the plans of M <= 500 are.
+            fpb = exe * 1e12 * (k_ms * 1e-3) / traffic
+            out["roofline"]["hbm_view"] = {"fetch_tb_per_s": round(traffic / (k_ms * 1e-3) / 1e12, 3), "hbm_peak_tb_per_s": HBM_PEAK_TBS,
+                                           "frac_of_hbm_peak": round(traffic / (k_ms * 1e-3) / 1e12 / HBM_PEAK_TBS, 4),
+                                           "flop_per_fetched_byte": round(fpb, 2),
+                                           "ridge_flop_per_byte": round(FP64_MFMA_PEAK_TFLOPS / HBM_PEAK_TBS, 2),
+                                           "binding_roof": "hbm" if fpb < FP64_MFMA_PEAK_TFLOPS / HBM_PEAK_TBS else "mfma",
+                                           "frac_of_binding_roof": round(exe / min(FP64_MFMA_PEAK_TFLOPS, fpb * HBM_PEAK_TBS), 4)}
         if per_rank is not None:
             # the N > 1 line: what every rank measured (the headline `value` is total flops / the slowest rank's wall time)
             kms = [r["kernel_ms"] for r in per_rank]
