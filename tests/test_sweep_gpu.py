@@ -202,6 +202,31 @@ def test_next_site_prepared_on_a_helper_thread(gpu, monkeypatch):
     assert capi.plan_cache_stats()[0] > 0  # the main thread's plan creations found the helper's plans
 
 
+def test_sweep_with_every_knob_off(gpu):
+    """the fallbacks behind the knobs stay alive: a fresh process with the vector cache, the buffer pool, the plan cache, the
+    retained heap, the helper threads, the fused Davidson step, the HIP graphs and the BLAS-pool limit all switched OFF by their
+    environment variables replays the N2 chain to the same energies"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "from block2_preview_amd import capi\n"
+        "from block2_preview_amd.sweep import DMRG, ChainFixture\n"
+        "capi.device_init(0)\n"
+        "fx = ChainFixture(%r)\n"
+        "dm = DMRG(fx, 'su2'); dm.init_environments(); dm.sweep(0, True); dm.sweep(1, False)\n"
+        "print('WORST %%.3e' %% max(abs(dm.energies[k] - e) for k, e in fx.ref_energy.items()), 'PREFETCHED', dm.n_prefetched)\n"
+    ) % (root, os.path.join(GOLDEN, "chain_n2su2", "n2c"))
+    env = dict(os.environ, B2X_VEC_CACHE_MB="0", B2X_HOST_HEAP="0", B2X_SWEEP_PREFETCH="0", B2X_DAV_FUSED="0", B2X_GRAPH="0",
+               B2X_HOST_BLAS_THREADS="0", B2X_POOL_MB="0", B2X_PLAN_CACHE_MB="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("WORST")][-1].split()
+    assert float(line[1]) < 1e-7 and int(line[3]) == 0
+
+
 def _ref_ndav(name):
     import json
 
