@@ -1199,6 +1199,8 @@ class SumMPODMRG:
                 if r.fx.peek() == "enoise":  # a noisy sweep: every rank recorded its own perturbative-noise step
                     noise.append(r.fx.next("enoise")[1])
                 parts.append(r._eff_ham(d))
+            for r in self.ranks[1:]:  # (rank 0 queues its own next site inside _solve; the others' helpers start here)
+                r._prefetch_next()
             e, ndav, psi, kinfo, _ = self.ranks[0]._solve(parts, noise or None)
             for r in self.ranks:
                 r._finish_site(isw, i, e, ndav, psi, kinfo)
