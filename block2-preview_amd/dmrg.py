@@ -118,6 +118,8 @@ class EffectiveHamiltonian:
         eng = self.me._eng
         t0 = time.perf_counter()
         eng.conv_thrd = conv_thrd
+        for other in self.me._engs[1:]:  # (sum-MPO: the other ranks' next site is prepared during this solve as well)
+            other._prefetch_next()
         e, ndav, psi, kinfo, n_pairs = eng._solve(self._parts, self._noise_event)
         tdav = time.perf_counter() - t0
         self._solved = (e, ndav, psi, kinfo)
