@@ -1287,8 +1287,8 @@ int b2x_vec_multi_dot(const double *const *vs, int nv, const double *x, size_t n
     if (rc != B2X_OK)
         return rc;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(launch_multidot(vs, nv, x, n, g_dot_partial, g_dot_out, st));
-    HIPCHK(hipMemcpyAsync(g_dot_host, g_dot_out, nv * sizeof(double), hipMemcpyDeviceToHost, st));
+    // (the second stage writes its few results straight into the pinned, device-visible host buffer: no copy operation)
+    HIPCHK(launch_multidot(vs, nv, x, n, g_dot_partial, g_dot_host, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(host_result, g_dot_host, nv * sizeof(double));
     return B2X_OK;
@@ -1301,8 +1301,7 @@ int b2x_vec_pair_dots(const double *const *us, const double *const *vs, int n_pa
     if (rc != B2X_OK)
         return rc;
     hipStream_t st = (hipStream_t)stream;
-    HIPCHK(launch_pairdot(us, vs, n_pairs, n, g_dot_partial, g_dot_out, st));
-    HIPCHK(hipMemcpyAsync(g_dot_host, g_dot_out, n_pairs * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(launch_pairdot(us, vs, n_pairs, n, g_dot_partial, g_dot_host, st));
     HIPCHK(hipStreamSynchronize(st));
     memcpy(host_result, g_dot_host, n_pairs * sizeof(double));
     return B2X_OK;
