@@ -1315,32 +1315,26 @@ int b2x_vec_ritz_olsen(const double *const *bs, const double *const *ss, int m, 
 }
 // out = (v - sum_j <b_j, v> b_j) / |.|, everything on the device and asynchronous on `stream`; *status (pinned host memory owned by
 // the library, see b2x_vec_gs_status) becomes 1 when the norm was not safely positive.
-static int *g_gs_flag_dev = nullptr, *g_gs_flag_host = nullptr;
+static int *g_gs_flag_host = nullptr; // pinned, device-visible: the kernel raises it in place (no copy operation)
 int b2x_vec_gs_finish(const double *const *bs, int m, const double *v, double *out, size_t n, void *stream) {
     if (m < 0 || m > 63 || (m && !bs) || !v || !out)
         return fail(B2X_ERR_INVALID, "b2x_vec_gs_finish: need 0 <= m <= 63");
     int rc = dot_scratch();
     if (rc != B2X_OK)
         return rc;
-    if (!g_gs_flag_dev) {
-        HIPCHK(hipMalloc((void **)&g_gs_flag_dev, sizeof(int)));
-        HIPCHK(hipMemset(g_gs_flag_dev, 0, sizeof(int)));
+    if (!g_gs_flag_host) {
         HIPCHK(hipHostMalloc((void **)&g_gs_flag_host, sizeof(int), hipHostMallocDefault));
         *g_gs_flag_host = 0;
     }
-    hipStream_t st = (hipStream_t)stream;
-    HIPCHK(launch_gs_finish(bs, m, v, g_dot_partial, g_dot_out, out, n, g_gs_flag_dev, st));
-    HIPCHK(hipMemcpyAsync(g_gs_flag_host, g_gs_flag_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(launch_gs_finish(bs, m, v, g_dot_partial, g_dot_out, out, n, g_gs_flag_host, (hipStream_t)stream));
     return B2X_OK;
 }
 int b2x_vec_gs_status(int *degenerate, int reset) {
     if (!degenerate)
         return fail(B2X_ERR_INVALID, "b2x_vec_gs_status: null argument");
-    *degenerate = g_gs_flag_host ? *g_gs_flag_host : 0;
-    if (reset && g_gs_flag_dev && *degenerate) {
-        HIPCHK(hipMemset(g_gs_flag_dev, 0, sizeof(int)));
-        *g_gs_flag_host = 0;
-    }
+    *degenerate = g_gs_flag_host ? *(volatile int *)g_gs_flag_host : 0;
+    if (reset && g_gs_flag_host)
+        *(volatile int *)g_gs_flag_host = 0; // (call after a wait on the stream: no finish kernel is in flight then)
     return B2X_OK;
 }
 int b2x_vec_dot(const double *x, const double *y, size_t n, double *host_result, void *stream) {
